@@ -1,0 +1,224 @@
+/*
+ * gss_hip.h -- C ABI of libgss_hip.so: the MI355X (gfx950) implementation of the
+ * pb_chime5 guided-source-separation hot path
+ *
+ *     STFT -> WPE -> CACGMM (guided EM) -> MVDR-Souden (+BAN) -> iSTFT
+ *
+ * i.e. everything /root/reference/pb_chime5/core.py:514-571
+ * (Enhancer.enhance_observation) executes per utterance.  The reference has no
+ * FFI layer of its own: its boundary is a set of Python callables that hand NumPy
+ * arrays to nara_wpe / pb_bss.  Each entry point below names the reference call
+ * it replaces (file:line).  The Python host package (pb_chime5_amd) binds this
+ * header with ctypes and keeps the reference's Python signatures on top of it.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative gss_status; the message
+ *    for the last failure on a context is available from gss_last_error().
+ *  - no C++ types, no exceptions, no torch types cross this boundary.
+ *  - one gss_ctx per GPU (per host thread); a context is not thread-safe,
+ *    different contexts are independent.  All work of a context is ordered on
+ *    one HIP stream (its own, or one adopted with gss_set_stream()).
+ *  - the caller owns every buffer it passes in.  Pointers named *_dev are device
+ *    pointers valid on the context's GPU (from gss_dev_malloc(), or any other
+ *    allocator of the same process, e.g. torch); pointers named *_host are host
+ *    pointers.  Device entry points are asynchronous on the context's stream and
+ *    never retain caller pointers after the work they enqueue has run.
+ *  - arithmetic type: float64 / complex128 end to end, like the reference
+ *    ("gss_cplx" = interleaved {re, im} doubles).
+ *
+ * Canonical device layouts (row-major, last index fastest)
+ *    time signal   x      (D, N)      double
+ *    STFT tensor   Y      (F, T, D)   gss_cplx      "FTD"; F = size/2 + 1
+ *    activity      act    (K, N)      uint8  (time)  /  (K, T) uint8 (frames)
+ *    posteriors    gamma  (F, K, T)   double
+ *    masks         m      (F, T)      double
+ *    beamformed    Xhat   (T, F)      gss_cplx       (the reference's layout)
+ * The reference's (D, T, F) / (K, T, F) / (T, F) layouts are produced / consumed
+ * with the gss_layout_* helpers.
+ */
+#ifndef GSS_HIP_H
+#define GSS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gss_ctx gss_ctx;
+typedef struct { double re, im; } gss_cplx;
+
+typedef enum {
+    GSS_OK = 0,
+    GSS_ERR_INVALID = -1,      /* bad argument (-> AssertionError / ValueError)   */
+    GSS_ERR_HIP = -2,          /* HIP runtime failure                              */
+    GSS_ERR_NOMEM = -3,        /* device allocation failed                         */
+    GSS_ERR_UNSUPPORTED = -4   /* configuration outside the built kernels          */
+                               /* (-> NotImplementedError)                         */
+} gss_status;
+
+/* Limits of the built kernels. */
+#define GSS_MAX_CHANNELS 32    /* reference asserts D < 30 (beamforming_wrapper.py:44) */
+#define GSS_MAX_CLASSES 8      /* pb_bss asserts K < 20; CHiME-5/6 use K <= 5           */
+#define GSS_MAX_STFT_SIZE 4096
+
+/* ---- context ----------------------------------------------------------- */
+int gss_create(int device_id, gss_ctx **ctx);
+int gss_destroy(gss_ctx *ctx);
+const char *gss_last_error(gss_ctx *ctx);
+const char *gss_version(void);
+/* Adopt an existing hipStream_t (e.g. torch's current stream); NULL restores the
+ * context's own stream. */
+int gss_set_stream(gss_ctx *ctx, void *hip_stream);
+int gss_synchronize(gss_ctx *ctx);
+
+/* ---- device memory plumbing (for hosts that have no allocator) ---------- */
+int gss_dev_malloc(gss_ctx *ctx, size_t bytes, void **dev_ptr);
+int gss_dev_free(gss_ctx *ctx, void *dev_ptr);
+int gss_memcpy_h2d(gss_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int gss_memcpy_d2h(gss_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int gss_memset(gss_ctx *ctx, void *dst_dev, int value, size_t bytes);
+
+/* ---- per-kernel timing (HIP events on the context's stream) -------------- */
+int gss_profile_enable(gss_ctx *ctx, int on);
+int gss_profile_reset(gss_ctx *ctx);
+/* Writes a JSON object {"kernel": {"calls": n, "ms": total}, ...} (synchronises). */
+int gss_profile_report(gss_ctx *ctx, char *buf, size_t buf_size);
+
+/* ---- STFT geometry ------------------------------------------------------- */
+/* Number of frames of nara_wpe.utils.stft(..., pad=True) (core.py:305-312). */
+int64_t gss_stft_num_frames(int64_t num_samples, int size, int shift, int fading);
+/* Output length of nara_wpe.utils.istft (core.py:314-321). */
+int64_t gss_istft_num_samples(int64_t num_frames, int size, int shift, int fading);
+/* nara_wpe.utils._samples_to_stft_frames (core.py:224-237). */
+int64_t gss_samples_to_stft_frames(int64_t samples, int size, int shift, int fading);
+
+/* Analysis / synthesis windows (host pointers, `size` doubles each).  The host
+ * computes them exactly like nara_wpe (periodic Blackman, biorthogonal synthesis
+ * window) so the library holds no window policy of its own. */
+int gss_set_windows(gss_ctx *ctx, int size, int shift,
+                    const double *analysis_host, const double *synthesis_host);
+
+/* ---- stage entry points (device pointers, asynchronous) ------------------ */
+
+/* A1  Enhancer.stft -> nara_wpe.utils.stft (core.py:305-312).
+ * x (D,N) -> Y (F,T,D), T = gss_stft_num_frames(N,...). */
+int gss_stft(gss_ctx *ctx, const double *x_dev, int D, int64_t N,
+             int fading, gss_cplx *Y_dev);
+
+/* A9  Enhancer.istft -> nara_wpe.utils.istft (core.py:314-321).
+ * X (T,F) -> x (gss_istft_num_samples(T,...)). */
+int gss_istft(gss_ctx *ctx, const gss_cplx *X_dev, int64_t T, int fading,
+              double *x_dev);
+
+/* A5' activity_time_to_frequency (database/chime5/database.py:409-472),
+ * stft_pad=True.  act (K,N) uint8 -> (K,T) uint8.  Bit-exact. */
+int gss_activity_time_to_frequency(gss_ctx *ctx, const uint8_t *act_dev, int K,
+                                   int64_t N, int fading, uint8_t *act_frames_dev);
+
+/* A2  WPE.__call__ -> nara_wpe.wpe.wpe_v8(statistics_mode='full',
+ * psd_context=0) (core.py:48-58).  Y (F,T,D) -> X (F,T,D); X may equal Y. */
+int gss_wpe(gss_ctx *ctx, const gss_cplx *Y_dev, int F, int64_t T, int D,
+            int taps, int delay, int iterations, gss_cplx *X_dev);
+
+/* A4-A6  GSS.__call__ (core.py:154-214): initialisation from the frame activity,
+ * CACGMMTrainer.fit(iterations, source_activity_mask) and the post step
+ * (iterations_post: 0 = masked predict, 1 = predict, >1 = extra unmasked fit
+ * iterations then predict).  Y (F,T,D), act_frames (K,T) -> gamma (F,K,T). */
+int gss_cacgmm(gss_ctx *ctx, const gss_cplx *Y_dev, int F, int64_t T, int D,
+               const uint8_t *act_frames_dev, int K, int iterations,
+               int iterations_post, double *gamma_dev);
+
+/* A0  mask post-processing of enhance_observation (core.py:537-554): zero the
+ * context frames, pick the target class, sum the others.
+ * gamma (F,K,T) -> target (F,T), distortion (F,T).  drop_context = 0 skips the
+ * zeroing (bf_drop_context=False). */
+int gss_masks_from_posteriors(gss_ctx *ctx, const double *gamma_dev, int F, int K,
+                              int64_t T, int target_index, int drop_context,
+                              int64_t start_context_frames,
+                              int64_t end_context_frames,
+                              double *target_mask_dev, double *distortion_mask_dev);
+
+/* A7+A8  beamform_mvdr_souden_from_masks (beamforming_wrapper.py:108-124) with
+ * eps=1e-10: masked PSD matrices, Souden MVDR, one reference channel from the
+ * cross-frequency SNR argmax, optional blind analytic normalisation, apply.
+ * Y (F,T,D), masks (F,T) -> Xhat (T,F).  ref_channel_dev (device int32, may be
+ * NULL) receives the chosen reference channel. */
+int gss_mvdr_souden(gss_ctx *ctx, const gss_cplx *Y_dev, int F, int64_t T, int D,
+                    const double *target_mask_dev,
+                    const double *distortion_mask_dev, int ban,
+                    gss_cplx *Xhat_dev, int32_t *ref_channel_dev);
+
+/* Layout helpers between the canonical device layouts and the reference's. */
+int gss_layout_dtf_to_ftd(gss_ctx *ctx, const gss_cplx *src_dev, int D, int64_t T,
+                          int F, gss_cplx *dst_dev);
+int gss_layout_ftd_to_dtf(gss_ctx *ctx, const gss_cplx *src_dev, int F, int64_t T,
+                          int D, gss_cplx *dst_dev);
+/* (A, B, C) double -> (C, A, B) double, e.g. gamma (F,K,T) -> (K,T,F) with
+ * A=F,B=K,C=T ... expressed as a generic 3-D permutation dst[p(i)] = src[i]:
+ * perm = 0: (A,B,C)->(B,C,A);  perm = 1: (A,B,C)->(C,A,B);  perm = 2: (A,B)->(B,A)
+ * (C = 1). */
+int gss_layout_permute_f64(gss_ctx *ctx, const double *src_dev, int64_t A,
+                           int64_t B, int64_t C, int perm, double *dst_dev);
+
+/* ---- fused per-utterance pipeline --------------------------------------- */
+typedef struct {
+    int stft_size;            /* 1024 */
+    int stft_shift;           /* 256  */
+    int stft_fading;          /* 1    */
+    int wpe;                  /* 1 = run WPE                                   */
+    int wpe_taps;             /* 10   */
+    int wpe_delay;            /* 2    */
+    int wpe_iterations;       /* 3    */
+    int bss_iterations;       /* 20   */
+    int bss_iterations_post;  /* 1    */
+    int bf_drop_context;      /* 1    */
+    int bf;                   /* 0 = 'mvdrSouden_ban', 1 = 'ch2', 2 = 'sum'    */
+    int postfilter;           /* 0 = None, 1 = 'mask_mul'                      */
+} gss_params;
+
+/* Optional taps into the pipeline's intermediates (device pointers; any may be
+ * NULL).  This is the `debug=True` contract of the reference blocks
+ * (core.py:85-86,210-212,275-276,568-569). */
+typedef struct {
+    gss_cplx *Obs_ftd;        /* (F,T,D) after WPE                             */
+    uint8_t *act_frames;      /* (K,T)                                         */
+    double *gamma;            /* (F,K,T) posteriors before context zeroing     */
+    double *target_mask;      /* (F,T)                                         */
+    double *distortion_mask;  /* (F,T)                                         */
+    gss_cplx *Xhat;           /* (T,F)                                         */
+    int32_t *ref_channel;     /* (1,)                                          */
+} gss_debug_taps;
+
+/* A0  Enhancer.enhance_observation (core.py:514-571), all intermediates kept in
+ * HBM.  obs (D,N) double, act (K,N) uint8 in dict order, target_index = position
+ * of speaker_id among the activity keys; start/end_context_samples as computed by
+ * start_end_context_frames (core.py:217-222).  out receives
+ * gss_istft_num_samples(T,...) samples. */
+int gss_enhance_observation(gss_ctx *ctx, const gss_params *params,
+                            const double *obs_dev, int D, int64_t N,
+                            const uint8_t *act_dev, int K, int target_index,
+                            int64_t start_context_samples,
+                            int64_t end_context_samples,
+                            double *out_dev, const gss_debug_taps *taps);
+
+/* Same, with host buffers: copies in, runs, copies out, synchronises. */
+int gss_enhance_observation_host(gss_ctx *ctx, const gss_params *params,
+                                 const double *obs_host, int D, int64_t N,
+                                 const uint8_t *act_host, int K, int target_index,
+                                 int64_t start_context_samples,
+                                 int64_t end_context_samples,
+                                 double *out_host);
+
+/* Bytes of context workspace the last call needed (diagnostics / sizing). */
+size_t gss_workspace_bytes(gss_ctx *ctx);
+
+/* Device self-test of the f64 MFMA fragment layout the WPE kernel relies on;
+ * returns 0 when the layout matches. */
+int gss_selftest_mfma(gss_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSS_HIP_H */

@@ -1,0 +1,264 @@
+"""ctypes binding of include/gss_hip.h (libgss_hip.so).
+
+This is the only place the Python host touches native code.  There is no CPU
+fallback: if the library is missing or no GPU is visible the product path raises.
+"""
+import ctypes
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+
+_LIB = None
+LIB_PATH = Path(__file__).resolve().parent / 'lib' / 'libgss_hip.so'
+
+GSS_OK = 0
+GSS_ERR_INVALID = -1
+GSS_ERR_HIP = -2
+GSS_ERR_NOMEM = -3
+GSS_ERR_UNSUPPORTED = -4
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_int64 = ctypes.c_int64
+c_size_t = ctypes.c_size_t
+
+
+class GssParams(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in (
+        'stft_size', 'stft_shift', 'stft_fading', 'wpe', 'wpe_taps', 'wpe_delay',
+        'wpe_iterations', 'bss_iterations', 'bss_iterations_post',
+        'bf_drop_context', 'bf', 'postfilter')]
+
+
+class GssDebugTaps(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        'Obs_ftd', 'act_frames', 'gamma', 'target_mask', 'distortion_mask',
+        'Xhat', 'ref_channel')]
+
+
+# name -> (restype, argtypes); every symbol include/gss_hip.h declares
+SIGNATURES = {
+    'gss_create': (c_int, [c_int, ctypes.POINTER(c_void_p)]),
+    'gss_destroy': (c_int, [c_void_p]),
+    'gss_last_error': (ctypes.c_char_p, [c_void_p]),
+    'gss_version': (ctypes.c_char_p, []),
+    'gss_set_stream': (c_int, [c_void_p, c_void_p]),
+    'gss_synchronize': (c_int, [c_void_p]),
+    'gss_dev_malloc': (c_int, [c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
+    'gss_dev_free': (c_int, [c_void_p, c_void_p]),
+    'gss_memcpy_h2d': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    'gss_memcpy_d2h': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    'gss_memset': (c_int, [c_void_p, c_void_p, c_int, c_size_t]),
+    'gss_profile_enable': (c_int, [c_void_p, c_int]),
+    'gss_profile_reset': (c_int, [c_void_p]),
+    'gss_profile_report': (c_int, [c_void_p, ctypes.c_char_p, c_size_t]),
+    'gss_stft_num_frames': (c_int64, [c_int64, c_int, c_int, c_int]),
+    'gss_istft_num_samples': (c_int64, [c_int64, c_int, c_int, c_int]),
+    'gss_samples_to_stft_frames': (c_int64, [c_int64, c_int, c_int, c_int]),
+    'gss_set_windows': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'gss_stft': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    'gss_istft': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'gss_activity_time_to_frequency': (
+        c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    'gss_wpe': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int,
+                        c_int, c_void_p]),
+    'gss_cacgmm': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p,
+                           c_int, c_int, c_int, c_void_p]),
+    'gss_masks_from_posteriors': (
+        c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int64,
+                c_int64, c_void_p, c_void_p]),
+    'gss_mvdr_souden': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int,
+                                c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'gss_layout_dtf_to_ftd': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int,
+                                      c_void_p]),
+    'gss_layout_ftd_to_dtf': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int,
+                                      c_void_p]),
+    'gss_layout_permute_f64': (c_int, [c_void_p, c_void_p, c_int64, c_int64,
+                                       c_int64, c_int, c_void_p]),
+    'gss_enhance_observation': (
+        c_int, [c_void_p, ctypes.POINTER(GssParams), c_void_p, c_int, c_int64,
+                c_void_p, c_int, c_int, c_int64, c_int64, c_void_p,
+                ctypes.POINTER(GssDebugTaps)]),
+    'gss_enhance_observation_host': (
+        c_int, [c_void_p, ctypes.POINTER(GssParams), c_void_p, c_int, c_int64,
+                c_void_p, c_int, c_int, c_int64, c_int64, c_void_p]),
+    'gss_workspace_bytes': (c_size_t, [c_void_p]),
+    'gss_selftest_mfma': (c_int, [c_void_p]),
+}
+
+
+class GssError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """Load libgss_hip.so (no GPU needed for loading) and declare prototypes."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = Path(path or os.environ.get('GSS_HIP_LIBRARY', LIB_PATH))
+    if not p.exists():
+        raise GssError(
+            f'{p} is missing: build it with `python -m pb_chime5_amd.build` '
+            '(there is no CPU fallback)')
+    lib = ctypes.CDLL(str(p))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def _raise(lib, ctx, status, what):
+    msg = lib.gss_last_error(ctx)
+    msg = msg.decode() if msg else ''
+    text = f'{what}: {msg}' if msg else what
+    # mirror the exception types of the reference
+    if status == GSS_ERR_INVALID:
+        if 'assert' in msg:
+            raise AssertionError(text)
+        raise ValueError(text)
+    if status == GSS_ERR_UNSUPPORTED:
+        raise NotImplementedError(text)
+    if status == GSS_ERR_NOMEM:
+        raise MemoryError(text)
+    raise GssError(text)
+
+
+class DeviceBuffer:
+    """A device allocation owned through the C ABI (gss_dev_malloc/free)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        ptr = c_void_p()
+        ctx._check(ctx.lib.gss_dev_malloc(ctx.handle, self.nbytes, ctypes.byref(ptr)),
+                   'gss_dev_malloc')
+        self.ptr = ptr.value
+
+    def free(self):
+        if self.ptr is not None and self.ctx.handle is not None:
+            self.ctx.lib.gss_dev_free(self.ctx.handle, c_void_p(self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One per GPU (and per host thread)."""
+
+    def __init__(self, device_id=0):
+        self.lib = load_library()
+        self.handle = None
+        h = c_void_p()
+        st = self.lib.gss_create(int(device_id), ctypes.byref(h))
+        if st != GSS_OK:
+            msg = self.lib.gss_last_error(None)
+            raise GssError(
+                f'gss_create(device {device_id}) failed: '
+                f'{msg.decode() if msg else st} -- the HIP path needs an AMD GPU '
+                '(there is no CPU fallback)')
+        self.handle = h
+        self.device_id = device_id
+        self._windows = None
+
+    # -- plumbing ----------------------------------------------------------
+    def _check(self, status, what):
+        if status != GSS_OK:
+            _raise(self.lib, self.handle, status, what)
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.gss_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._check(self.lib.gss_synchronize(self.handle), 'gss_synchronize')
+
+    def set_stream(self, stream_handle):
+        self._check(self.lib.gss_set_stream(self.handle, c_void_p(stream_handle)),
+                    'gss_set_stream')
+
+    def empty(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, array):
+        a = np.ascontiguousarray(array)
+        buf = DeviceBuffer(self, max(a.nbytes, 16))
+        if a.nbytes:
+            self._check(self.lib.gss_memcpy_h2d(
+                self.handle, c_void_p(buf.ptr), a.ctypes.data_as(c_void_p), a.nbytes),
+                'gss_memcpy_h2d')
+        return buf
+
+    def upload(self, buf, array):
+        a = np.ascontiguousarray(array)
+        assert a.nbytes <= buf.nbytes
+        self._check(self.lib.gss_memcpy_h2d(
+            self.handle, c_void_p(buf.ptr), a.ctypes.data_as(c_void_p), a.nbytes),
+            'gss_memcpy_h2d')
+
+    def to_host(self, buf, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= buf.nbytes, (out.nbytes, buf.nbytes)
+        if out.nbytes:
+            self._check(self.lib.gss_memcpy_d2h(
+                self.handle, out.ctypes.data_as(c_void_p), c_void_p(buf.ptr), out.nbytes),
+                'gss_memcpy_d2h')
+        return out
+
+    # -- profiling ---------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self.lib.gss_profile_enable(self.handle, int(on)), 'profile_enable')
+
+    def profile_reset(self):
+        self._check(self.lib.gss_profile_reset(self.handle), 'profile_reset')
+
+    def profile_report(self):
+        buf = ctypes.create_string_buffer(1 << 16)
+        self._check(self.lib.gss_profile_report(self.handle, buf, len(buf)),
+                    'profile_report')
+        return json.loads(buf.value.decode())
+
+    def workspace_bytes(self):
+        return int(self.lib.gss_workspace_bytes(self.handle))
+
+    # -- STFT tables -------------------------------------------------------
+    def set_windows(self, size, shift, analysis, synthesis):
+        key = (size, shift, analysis.tobytes(), synthesis.tobytes())
+        if self._windows == key:
+            return
+        a = np.ascontiguousarray(analysis, dtype=np.float64)
+        s = np.ascontiguousarray(synthesis, dtype=np.float64)
+        assert a.shape == (size,) and s.shape == (size,)
+        self._check(self.lib.gss_set_windows(
+            self.handle, size, shift, a.ctypes.data_as(c_void_p),
+            s.ctypes.data_as(c_void_p)), 'gss_set_windows')
+        self._windows = key
+
+
+_DEFAULT_CTX = {}
+
+
+def default_context(device_id=None):
+    """Process-wide context for ``device_id`` (default: $GSS_DEVICE or LOCAL_RANK or 0)."""
+    if device_id is None:
+        device_id = int(os.environ.get('GSS_DEVICE', os.environ.get('LOCAL_RANK', 0)))
+    ctx = _DEFAULT_CTX.get(device_id)
+    if ctx is None or ctx.handle is None:
+        ctx = _DEFAULT_CTX[device_id] = Context(device_id)
+    return ctx

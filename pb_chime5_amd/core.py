@@ -1,0 +1,445 @@
+"""Per-utterance guided source separation with the reference's Python surface
+(/root/reference/pb_chime5/core.py), running on MI355X.
+
+Legend (as in the reference):  n, N time | t, T frame | f, F frequency |
+d, D channel | a, A array | k, K class (speakers + ``Noise``).
+
+Kept from the reference: ``get_enhancer(**same kwargs)``, the ``WPE`` / ``GSS`` /
+``Beamformer`` / ``Enhancer`` blocks with their call signatures, shapes, dtypes
+(complex128 / float64 at the Python edge) and exception types,
+``start_end_context_frames`` and the ``debug=True`` contract (intermediates kept
+on the block).  Different by design: the numeric work is done by hand-written HIP
+kernels behind ``include/gss_hip.h``; ``Enhancer.enhance_observation`` uses the
+fused device pipeline (one H2D of the time signal, one D2H of the result) unless
+a block was replaced or ``fused=False`` is passed; work is distributed over GPUs
+by ``pb_chime5_amd.parallel`` instead of ``dlp_mpi``.
+"""
+from dataclasses import dataclass, field
+from pathlib import Path
+
+import numpy as np
+
+from pb_chime5_amd import mapping, ops
+from pb_chime5_amd.database.chime5 import activity_time_to_frequency
+from pb_chime5_amd.io import dump_audio, load_audio
+from pb_chime5_amd.utils.numpy_utils import morph
+
+
+@dataclass
+class WPE:
+    """core.py:41-88 -> nara_wpe.wpe.wpe_v8."""
+    taps: int
+    delay: int
+    iterations: int
+    psd_context: int
+
+    def __call__(self, Obs, stack=None, debug=False):
+        kw = dict(taps=self.taps, delay=self.delay, iterations=self.iterations,
+                  psd_context=self.psd_context)
+        if Obs.ndim == 3:
+            assert stack is None, stack
+            Obs = ops.wpe_dtf(Obs, **kw)
+        elif Obs.ndim == 4:
+            if stack is True:
+                _A = Obs.shape[0]
+                Obs = morph('ACTF->A*CTF', Obs)
+                Obs = ops.wpe_dtf(Obs, **kw)
+                Obs = morph('A*CTF->ACTF', Obs, A=_A)
+            elif stack is False:
+                Obs = np.array([ops.wpe_dtf(o, **kw) for o in Obs])
+            else:
+                raise NotImplementedError(stack)
+        else:
+            raise NotImplementedError(Obs.shape)
+        if debug:
+            self.locals = locals()
+        return Obs
+
+
+@dataclass
+class Activity:
+    """core.py:91-141.  The hot path only consumes
+    ``activity[session_id][array][speaker][start:stop] -> bool array``; anything
+    with that interface can be plugged in through ``store``.  ``type='path'``
+    reads the reference's per-session pickles.  Building the store from the CHiME
+    JSON (``type='annotation'``) is dataset preparation and out of scope."""
+    type: str = 'annotation'
+    garbage_class: bool = False
+    database_path: str = None
+    path: str = None
+    store: dict = None
+
+    def __getitem__(self, session_id):
+        if self.store is not None:
+            return self.store[session_id]
+        if self.type == 'path':
+            import pickle
+            with open(Path(self.path) / f'{session_id}.pkl', 'rb') as fd:
+                return pickle.load(fd)
+        if self.type == 'annotation':
+            raise NotImplementedError(
+                "Activity(type='annotation') needs the CHiME-5 JSON database, which "
+                'this build does not parse; pass Activity(store=...) or type="path".')
+        raise ValueError(self.type)
+
+
+@dataclass
+class GSS:
+    """core.py:144-214 -> CACGMMTrainer.fit / predict for every frequency."""
+    iterations: int
+    iterations_post: int
+    verbose: bool = True
+
+    def __call__(self, Obs, acitivity_freq, debug=False):
+        posterior = ops.cacgmm_posteriors(
+            Obs, acitivity_freq, iterations=self.iterations,
+            iterations_post=self.iterations_post)
+        if debug:
+            initialization = np.asarray(acitivity_freq, dtype=np.float64)
+            initialization = np.where(initialization == 0, 1e-10, initialization)
+            initialization = initialization / np.sum(initialization, keepdims=True, axis=0)
+            source_active_mask = np.asarray(acitivity_freq, dtype=bool)
+            self.locals = locals()
+        return posterior
+
+
+def start_end_context_samples(ex):
+    """The sample counts core.py:218-222 derives from ``ex`` (asserted >= 0)."""
+    start_context_samples = ex['start_orig']['original'] - ex['start']['original']
+    end_context_samples = ex['end']['original'] - ex['end_orig']['original']
+    assert start_context_samples >= 0, (start_context_samples, ex)
+    assert end_context_samples >= 0, (end_context_samples, ex)
+    return start_context_samples, end_context_samples
+
+
+def start_end_context_frames(ex, stft_size, stft_shift, stft_fading):
+    """core.py:217-238."""
+    start, end = start_end_context_samples(ex)
+    return (
+        ops.samples_to_stft_frames(start, stft_size, stft_shift, fading=stft_fading),
+        ops.samples_to_stft_frames(end, stft_size, stft_shift, fading=stft_fading),
+    )
+
+
+@dataclass
+class Beamformer:
+    """core.py:241-278."""
+    type: str
+    postfilter: str
+
+    def __call__(self, Obs, target_mask, distortion_mask, debug=False):
+        bf = self.type
+        if bf == 'mvdrSouden_ban':
+            from pb_chime5_amd.speech_enhancement.beamforming_wrapper import (
+                beamform_mvdr_souden_from_masks)
+            X_hat = beamform_mvdr_souden_from_masks(
+                Y=Obs, X_mask=target_mask, N_mask=distortion_mask, ban=True)
+        elif bf == 'ch2':
+            X_hat = Obs[2]
+        elif bf == 'sum':
+            X_hat = np.sum(Obs, axis=0)
+        else:
+            raise NotImplementedError(bf)
+
+        if self.postfilter is None:
+            pass
+        elif self.postfilter == 'mask_mul':
+            X_hat = X_hat * target_mask
+        else:
+            raise NotImplementedError(self.postfilter)
+        if debug:
+            self.locals = locals()
+        return X_hat
+
+
+@dataclass
+class Enhancer:
+    """core.py:281-571."""
+    wpe_block: WPE
+    activity: Activity
+    gss_block: GSS
+    bf_block: Beamformer
+
+    bf_drop_context: bool
+
+    stft_size: int
+    stft_shift: int
+    stft_fading: bool
+
+    context_samples: int
+    multiarray: bool
+    reference_array: [None, str]
+
+    device_id: int = None
+    iterator_factory: object = field(default=None, repr=False)
+
+    # ------------------------------------------------------------------ STFT
+    def stft(self, x):
+        return ops.stft(x, size=self.stft_size, shift=self.stft_shift,
+                        fading=self.stft_fading, ctx=self._ctx())
+
+    def istft(self, X):
+        return ops.istft(X, size=self.stft_size, shift=self.stft_shift,
+                         fading=self.stft_fading, ctx=self._ctx())
+
+    def _ctx(self):
+        from pb_chime5_amd._capi import default_context
+        return default_context(self.device_id)
+
+    # ------------------------------------------------------------------ sessions
+    def get_iterator(self, session_id):
+        """The reference builds this from its JSON database (core.py:323-331).
+        Here an ``iterator_factory(session_ids, context_samples)`` yielding the same
+        ``ex`` dicts has to be supplied (dataset plumbing is out of scope)."""
+        if self.iterator_factory is None:
+            raise RuntimeError(
+                'No example source: construct the Enhancer with '
+                'iterator_factory=callable(session_ids, context_samples) -> sequence '
+                'of example dicts (the CHiME JSON database layer is not part of '
+                'this build).')
+        return self.iterator_factory(session_id, self.context_samples)
+
+    def enhance_session(self, session_ids, audio_dir, dataset_slice=False,
+                        audio_dir_exist_ok=False):
+        """core.py:333-394; examples are sharded over the visible GPUs by
+        pb_chime5_amd.parallel when more than one process is running."""
+        from pb_chime5_amd import parallel
+        audio_dir = Path(audio_dir)
+        it = self.get_iterator(session_ids)
+
+        if parallel.is_master():
+            audio_dir.mkdir(exist_ok=audio_dir_exist_ok)
+            for dataset in set(mapping.session_to_dataset.values()):
+                (audio_dir / dataset).mkdir(exist_ok=audio_dir_exist_ok)
+        parallel.barrier()
+
+        if dataset_slice is not False:
+            if dataset_slice is True:
+                it = it[:2]
+            elif isinstance(dataset_slice, int):
+                it = it[:dataset_slice]
+            elif isinstance(dataset_slice, slice):
+                it = it[dataset_slice]
+            else:
+                raise ValueError(dataset_slice)
+
+        for ex in parallel.split_managed(it):
+            x_hat = self.enhance_example(ex)
+            example_id = ex['example_id']
+            session_id = ex['session_id']
+            dataset = mapping.session_to_dataset[session_id]
+            if x_hat.ndim == 1:
+                dump_audio(x_hat, audio_dir / f'{dataset}' / f'{example_id}.wav')
+            else:
+                raise NotImplementedError(x_hat.shape)
+
+    # ------------------------------------------------------------------ examples
+    def enhance_example(self, ex, debug=False):
+        """core.py:396-512."""
+        session_id = ex['session_id']
+        reference_array = self.reference_array
+        if reference_array is None:
+            try:
+                reference_array = ex['reference_array']
+            except KeyError:
+                raise RuntimeError(
+                    'Failed to get the "reference_array" from the example.\n'
+                    'Probably you tried to enhance the "train" dataset.\n'
+                    'Train has no "reference_array".\n'
+                    'You can set a "reference_array" with get_enhancer('
+                    'reference_array="U06").\n'
+                    'In case of multiarray, the reference array is used for the '
+                    'projection of the human annotations.') from None
+        speaker_id = ex['speaker_id']
+
+        array_start = ex['start']['observation'][reference_array]
+        array_end = ex['end']['observation'][reference_array]
+        ex_array_activity = {
+            k: arr[array_start:min(array_end, len(arr))]
+            for k, arr in self.activity[session_id][reference_array].items()
+        }
+
+        def load_arrays(select):
+            arrays = [
+                load_audio(ex['audio_path']['observation'][array],
+                           start=ex['start']['observation'][array],
+                           stop=ex['end']['observation'][array])
+                for array in sorted(ex['audio_path']['observation'].keys())
+            ]
+            # The context does not consider the end of an utterance: arrays can
+            # differ in length, cut to the shortest.
+            assert {v.ndim for v in arrays} == {2}, [v.shape for v in arrays]
+            time_length = min(v.shape[-1] for v in arrays)
+            return morph('ACN->A*CN', np.array(
+                [select(v)[..., :time_length] for v in arrays]))
+
+        if self.multiarray is True:
+            obs = load_arrays(lambda v: v)
+        elif self.multiarray == 'outer_array_mics':
+            obs = load_arrays(lambda v: v[(0, -1), :])
+        elif self.multiarray == 'first_array_mics':
+            obs = load_arrays(lambda v: v[(0,), :])
+        elif self.multiarray is False:
+            obs = load_audio(ex['audio_path']['observation'][reference_array],
+                             start=ex['start']['observation'][reference_array],
+                             stop=ex['end']['observation'][reference_array])
+        else:
+            raise ValueError(self.multiarray)
+
+        x_hat = self.enhance_observation(
+            obs, ex_array_activity=ex_array_activity, speaker_id=speaker_id, ex=ex,
+            debug=debug)
+
+        if self.context_samples > 0:
+            start_orig = ex['start_orig']['observation'][reference_array]
+            start = ex['start']['observation'][reference_array]
+            start_context = start_orig - start
+            num_samples_orig = ex['num_samples_orig']['observation'][reference_array]
+            x_hat = x_hat[..., start_context:start_context + num_samples_orig]
+
+        if debug:
+            self.enhance_example_locals = locals()
+        return x_hat
+
+    # ------------------------------------------------------------------ the hot path
+    def _fusable(self):
+        return (
+            (self.wpe_block is None or type(self.wpe_block) is WPE)
+            and type(self.gss_block) is GSS and type(self.bf_block) is Beamformer
+            and (self.wpe_block is None or self.wpe_block.psd_context == 0)
+        )
+
+    def _params(self):
+        w = self.wpe_block
+        return ops.make_params(
+            stft_size=self.stft_size, stft_shift=self.stft_shift,
+            stft_fading=self.stft_fading, wpe=w is not None,
+            wpe_taps=w.taps if w else 10, wpe_delay=w.delay if w else 2,
+            wpe_iterations=w.iterations if w else 3,
+            bss_iterations=self.gss_block.iterations,
+            bss_iterations_post=self.gss_block.iterations_post,
+            bf_drop_context=self.bf_drop_context, bf=self.bf_block.type,
+            postfilter=self.bf_block.postfilter)
+
+    def enhance_observation(self, obs, ex_array_activity, speaker_id, ex=None,
+                            debug=False, fused=None):
+        """core.py:514-571.  obs (D,N) float64, ex_array_activity dict
+        speaker -> bool (N,), returns x_hat (N',) float64."""
+        if fused is None:
+            fused = self._fusable()
+        if not fused:
+            return self._enhance_observation_blocks(obs, ex_array_activity, speaker_id,
+                                                    ex, debug)
+        target_speaker_index = tuple(ex_array_activity.keys()).index(speaker_id)
+        activity = np.array(list(ex_array_activity.values()))
+        start_ctx = end_ctx = 0
+        if self.bf_drop_context:
+            start_ctx, end_ctx = start_end_context_samples(ex)
+        params = self._params()     # raises NotImplementedError for unknown bf / postfilter
+        res = ops.enhance_observation(
+            obs, activity, target_speaker_index, start_ctx, end_ctx, params=params,
+            debug=debug, ctx=self._ctx())
+        if not debug:
+            return res
+        x_hat, details = res
+        Obs = details['Obs']
+        acitivity_freq = details['acitivity_freq']
+        target_mask = details['target_mask']
+        distortion_mask = details['distortion_mask']
+        X_hat = details['X_hat']
+        masks = details['posterior'].copy()
+        if self.bf_drop_context:
+            start_context_frames, end_context_frames = start_end_context_frames(
+                ex, self.stft_size, self.stft_shift, self.stft_fading)
+            masks[:, :start_context_frames, :] = 0
+            if end_context_frames > 0:
+                masks[:, -end_context_frames:, :] = 0
+        self.enhance_observation_locals = locals()
+        return x_hat
+
+    def _enhance_observation_blocks(self, obs, ex_array_activity, speaker_id, ex, debug):
+        """Block-by-block path with the reference's control flow (one device
+        round trip per block); used when a block was swapped out."""
+        Obs = self.stft(obs)
+        if self.wpe_block is not None:
+            Obs = self.wpe_block(Obs, debug=debug)
+        acitivity_freq = activity_time_to_frequency(
+            np.array(list(ex_array_activity.values())),
+            stft_window_length=self.stft_size, stft_shift=self.stft_shift,
+            stft_fading=self.stft_fading, stft_pad=True)
+        masks = self.gss_block(Obs, acitivity_freq, debug=debug)
+        if self.bf_drop_context:
+            start_context_frames, end_context_frames = start_end_context_frames(
+                ex, stft_size=self.stft_size, stft_shift=self.stft_shift,
+                stft_fading=self.stft_fading)
+            masks[:, :start_context_frames, :] = 0
+            if end_context_frames > 0:
+                masks[:, -end_context_frames:, :] = 0
+        target_speaker_index = tuple(ex_array_activity.keys()).index(speaker_id)
+        target_mask = masks[target_speaker_index]
+        distortion_mask = np.sum(np.delete(masks, target_speaker_index, axis=0), axis=0)
+        X_hat = self.bf_block(Obs, target_mask=target_mask,
+                              distortion_mask=distortion_mask, debug=debug)
+        x_hat = self.istft(X_hat)
+        if debug:
+            self.enhance_observation_locals = locals()
+        return x_hat
+
+
+def get_enhancer(
+    multiarray=False,
+    reference_array=None,
+    context_samples=240000,
+
+    wpe=True,
+    wpe_tabs=10,
+    wpe_delay=2,
+    wpe_iterations=3,
+    wpe_psd_context=0,
+
+    activity_type='annotation',
+    activity_path=None,
+    activity_garbage_class=True,
+
+    stft_size=1024,
+    stft_shift=256,
+    stft_fading=True,
+
+    bss_iterations=20,
+    bss_iterations_post=1,
+
+    bf_drop_context=True,
+
+    bf='mvdrSouden_ban',
+    postfilter=None,
+
+    database_path=None,
+
+    activity_store=None,
+    iterator_factory=None,
+    device_id=None,
+):
+    """core.py:574-637 (same keyword arguments and defaults; ``activity_store``,
+    ``iterator_factory`` and ``device_id`` are additions)."""
+    assert wpe is True or wpe is False, wpe
+    assert activity_path is None or activity_type == 'path', (activity_path, activity_type)
+
+    return Enhancer(
+        multiarray=multiarray,
+        reference_array=reference_array,
+        context_samples=context_samples,
+        wpe_block=WPE(taps=wpe_tabs, delay=wpe_delay, iterations=wpe_iterations,
+                      psd_context=wpe_psd_context) if wpe else None,
+        activity=Activity(type=activity_type, garbage_class=activity_garbage_class,
+                          path=activity_path, database_path=database_path,
+                          store=activity_store),
+        gss_block=GSS(iterations=bss_iterations, iterations_post=bss_iterations_post,
+                      verbose=False),
+        bf_drop_context=bf_drop_context,
+        bf_block=Beamformer(type=bf, postfilter=postfilter),
+        stft_size=stft_size,
+        stft_shift=stft_shift,
+        stft_fading=stft_fading,
+        device_id=device_id,
+        iterator_factory=iterator_factory,
+    )

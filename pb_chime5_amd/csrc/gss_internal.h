@@ -1,0 +1,185 @@
+// Internal declarations shared by the HIP translation units of libgss_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gss_hip.h"
+
+typedef double2 cplx;  // .x = re, .y = im; bit-compatible with gss_cplx
+
+#define GSS_TINY 2.2250738585072014e-308  // np.finfo(np.float64).tiny
+
+// ---------------------------------------------------------------- device math
+__device__ __forceinline__ cplx c_make(double r, double i) { return make_double2(r, i); }
+__device__ __forceinline__ cplx c_add(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx c_sub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cplx c_mul(cplx a, cplx b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// a * conj(b)
+__device__ __forceinline__ cplx c_mulc(cplx a, cplx b) {
+    return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+// conj(a) * b
+__device__ __forceinline__ cplx c_cmul(cplx a, cplx b) {
+    return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ cplx c_scale(cplx a, double s) { return make_double2(a.x * s, a.y * s); }
+__device__ __forceinline__ cplx c_conj(cplx a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ double c_abs2(cplx a) { return a.x * a.x + a.y * a.y; }
+// acc += a * b
+__device__ __forceinline__ void c_fma(cplx &acc, cplx a, cplx b) {
+    acc.x = fma(a.x, b.x, acc.x);
+    acc.x = fma(-a.y, b.y, acc.x);
+    acc.y = fma(a.x, b.y, acc.y);
+    acc.y = fma(a.y, b.x, acc.y);
+}
+// acc += a * conj(b)
+__device__ __forceinline__ void c_fmac(cplx &acc, cplx a, cplx b) {
+    acc.x = fma(a.x, b.x, acc.x);
+    acc.x = fma(a.y, b.y, acc.x);
+    acc.y = fma(a.y, b.x, acc.y);
+    acc.y = fma(-a.x, b.y, acc.y);
+}
+// acc += conj(a) * b
+__device__ __forceinline__ void c_cfma(cplx &acc, cplx a, cplx b) {
+    acc.x = fma(a.x, b.x, acc.x);
+    acc.x = fma(a.y, b.y, acc.x);
+    acc.y = fma(a.x, b.y, acc.y);
+    acc.y = fma(-a.y, b.x, acc.y);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Upper-triangular packed index of (d1 <= d2) in a D x D Hermitian matrix.
+__host__ __device__ __forceinline__ int tri_index(int d1, int d2, int D) {
+    return d1 * D - (d1 * (d1 - 1)) / 2 + (d2 - d1);
+}
+__host__ __device__ __forceinline__ int tri_count(int D) { return D * (D + 1) / 2; }
+
+// ---------------------------------------------------------------- context
+struct ProfEntry {
+    std::string name;
+    hipEvent_t start, stop;
+};
+
+struct gss_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string error;
+
+    // bump arena for intermediates of one top-level call
+    char *arena = nullptr;
+    size_t arena_size = 0;
+    size_t arena_off = 0;
+    size_t arena_peak = 0;
+
+    // STFT tables
+    int stft_size = 0, stft_shift = 0;
+    double *win_analysis = nullptr;   // device, stft_size
+    double *win_synthesis = nullptr;  // device, stft_size
+    cplx *twiddle = nullptr;          // device, stft_size/2: exp(-2 pi i j / size)
+
+    // profiling
+    bool profiling = false;
+    std::vector<ProfEntry> prof_pending;
+    std::vector<hipEvent_t> event_pool;
+    std::map<std::string, std::pair<long, double>> prof_acc;
+};
+
+int gss_fail(gss_ctx *ctx, int code, const char *fmt, ...);
+
+#define GSS_HIP_CHECK(ctx, expr)                                                   \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess)                                                      \
+            return gss_fail((ctx), GSS_ERR_HIP, "%s failed: %s (%s:%d)", #expr,    \
+                            hipGetErrorString(_e), __FILE__, __LINE__);            \
+    } while (0)
+
+#define GSS_REQUIRE(ctx, cond, code, ...)                      \
+    do {                                                       \
+        if (!(cond)) return gss_fail((ctx), (code), __VA_ARGS__); \
+    } while (0)
+
+#define GSS_TRY(expr)              \
+    do {                           \
+        int _s = (expr);           \
+        if (_s != GSS_OK) return _s; \
+    } while (0)
+
+// Arena: reserve() makes sure `bytes` are available for the coming top-level call
+// (may synchronise + reallocate); alloc() bumps.  reset() starts a new call.
+int arena_reserve(gss_ctx *ctx, size_t bytes);
+void arena_reset(gss_ctx *ctx);
+void *arena_alloc(gss_ctx *ctx, size_t bytes);
+template <typename T>
+static inline T *arena_alloc_t(gss_ctx *ctx, size_t count) {
+    return reinterpret_cast<T *>(arena_alloc(ctx, count * sizeof(T)));
+}
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// Profiling scope: records HIP events around a launch when enabled.
+struct ProfScope {
+    gss_ctx *ctx;
+    ProfEntry e;
+    bool active;
+    ProfScope(gss_ctx *c, const char *name);
+    ~ProfScope();
+};
+#define GSS_PROF(ctx, name) ProfScope _prof_scope_##__LINE__((ctx), (name))
+
+// Post-launch error check.
+#define GSS_LAUNCH_CHECK(ctx, name)                                               \
+    do {                                                                          \
+        hipError_t _e = hipGetLastError();                                        \
+        if (_e != hipSuccess)                                                     \
+            return gss_fail((ctx), GSS_ERR_HIP, "launch of %s failed: %s", (name), \
+                            hipGetErrorString(_e));                               \
+    } while (0)
+
+// ---------------------------------------------------------------- stage launchers
+// (device pointers, workspace from the arena, asynchronous on ctx->stream)
+size_t wpe_workspace_bytes(int F, int64_t T, int D, int taps, int delay);
+int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int delay,
+            int iterations, cplx *X);
+
+size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K);
+int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8_t *act,
+               int K, int iterations, int iterations_post, double *gamma);
+
+size_t mvdr_workspace_bytes(int F, int64_t T, int D);
+int mvdr_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double *mx,
+             const double *mn, int ban, cplx *Xhat, int32_t *ref_channel);
+int masks_from_posteriors_run(gss_ctx *ctx, const double *gamma, int F, int K, int64_t T,
+                              int target, int drop, int64_t start_frames,
+                              int64_t end_frames, double *mx, double *mn);
+
+size_t stft_workspace_bytes(int64_t T, int size);
+int stft_run(gss_ctx *ctx, const double *x, int D, int64_t N, int fading, cplx *Y);
+int istft_run(gss_ctx *ctx, const cplx *X, int64_t T, int fading, double *x);
+int activity_run(gss_ctx *ctx, const uint8_t *act, int K, int64_t N, int fading,
+                 uint8_t *out);
+int channel_pick_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int mode,
+                     cplx *Xhat);  // mode 1: 'ch2', 2: 'sum'
+int mask_mul_run(gss_ctx *ctx, cplx *Xhat, const double *mask_ft, int F, int64_t T);
+
+int selftest_mfma_run(gss_ctx *ctx);
+
+// Shared device routine: cyclic-Jacobi eigendecomposition of Hermitian matrices
+// held in LDS (see jacobi.h).

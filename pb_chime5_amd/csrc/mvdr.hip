@@ -1,0 +1,503 @@
+// Mask post-processing and mask-based MVDR (Souden) beamforming with blind
+// analytic normalisation:
+//   enhance_observation mask handling            core.py:537-554
+//   beamform_mvdr_souden_from_masks / _Beamformer speech_enhancement/beamforming_wrapper.py:11-124
+//   -> pb_bss.extraction.beamformer.{get_power_spectral_density_matrix,
+//      get_mvdr_vector_souden(eps=1e-10), blind_analytic_normalization,
+//      apply_beamforming_vector}
+#include "gss_internal.h"
+#include "jacobi.h"
+
+namespace {
+
+constexpr int PSD_TILE = 64;
+constexpr int PSD_TS = PSD_TILE + 1;
+constexpr int PSD_SLOTS = 3;
+
+// gamma (F,K,T) -> target (F,T), distortion (F,T); Python slice semantics for the
+// zeroed context frames (masks[:, :start] = 0; if end > 0: masks[:, -end:] = 0).
+__global__ void masks_kernel(const double *__restrict__ gamma, int F, int K, int64_t T,
+                             int target, int64_t zero_lo_end, int64_t zero_hi_begin,
+                             double *__restrict__ mx, double *__restrict__ mn) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)F * T) return;
+    const int f = idx / T;
+    const int64_t t = idx - (int64_t)f * T;
+    double x = 0.0, n = 0.0;
+    if (t >= zero_lo_end && t < zero_hi_begin) {
+        const double *g = gamma + (int64_t)f * K * T + t;
+        x = g[(int64_t)target * T];
+        for (int k = 0; k < K; ++k)
+            if (k != target) n += g[(int64_t)k * T];
+    }
+    mx[idx] = x;
+    mn[idx] = n;
+}
+
+// Partial sums of  m_X(t) y y^H,  m_N(t) y y^H,  m_X(t),  m_N(t)  over a chunk of
+// frames; upper triangle only.  grid (chunks, F), block 256.
+__global__ __launch_bounds__(256) void psd_kernel(const cplx *__restrict__ Y,
+                                                  const double *__restrict__ mx,
+                                                  const double *__restrict__ mn, int64_t T, int D,
+                                                  int NE, int nch, int chunk_frames,
+                                                  cplx *__restrict__ part,
+                                                  double *__restrict__ msum) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx *ys = reinterpret_cast<cplx *>(smem);                      // D * PSD_TS
+    double *wk = reinterpret_cast<double *>(ys + D * PSD_TS);       // 2 * PSD_TILE
+    unsigned char *ed = reinterpret_cast<unsigned char *>(wk + 2 * PSD_TILE);
+    const int f = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int tl = tid & 63, g = tid >> 6;
+    const int64_t c0 = (int64_t)chunk * chunk_frames;
+    const int64_t c1 = c0 + chunk_frames < T ? c0 + chunk_frames : T;
+    const cplx *Yf = Y + (int64_t)f * T * D;
+
+    for (int d1 = tid; d1 < D; d1 += blockDim.x)
+        for (int d2 = d1; d2 < D; ++d2) {
+            const int e = tri_index(d1, d2, D);
+            ed[2 * e] = (unsigned char)d1;
+            ed[2 * e + 1] = (unsigned char)d2;
+        }
+    cplx acc[PSD_SLOTS][2];
+#pragma unroll
+    for (int s = 0; s < PSD_SLOTS; ++s) acc[s][0] = acc[s][1] = c_make(0.0, 0.0);
+    double sx = 0.0, sn = 0.0;
+
+    for (int64_t t0 = c0; t0 < c1; t0 += PSD_TILE) {
+        __syncthreads();
+        const int64_t t = t0 + tl;
+        for (int d = g; d < D; d += 4)
+            ys[d * PSD_TS + tl] = t < c1 ? Yf[t * D + d] : c_make(0.0, 0.0);
+        if (g == 0) {
+            const double a = t < c1 ? mx[(int64_t)f * T + t] : 0.0;
+            const double b = t < c1 ? mn[(int64_t)f * T + t] : 0.0;
+            wk[tl] = a;
+            wk[PSD_TILE + tl] = b;
+            sx += a;
+            sn += b;
+        }
+        __syncthreads();
+        const int nfr = (int)min((int64_t)PSD_TILE, c1 - t0);
+#pragma unroll
+        for (int s = 0; s < PSD_SLOTS; ++s) {
+            const int e = tid + 256 * s;
+            if (e < NE) {
+                const cplx *r1 = ys + ed[2 * e] * PSD_TS;
+                const cplx *r2 = ys + ed[2 * e + 1] * PSD_TS;
+                for (int j = 0; j < nfr; ++j) {
+                    const cplx y1 = r1[j], y2 = r2[j];
+                    const double pr = y1.x * y2.x + y1.y * y2.y;
+                    const double pim = y1.y * y2.x - y1.x * y2.y;
+                    const double a = wk[j], b = wk[PSD_TILE + j];
+                    acc[s][0].x = fma(a, pr, acc[s][0].x);
+                    acc[s][0].y = fma(a, pim, acc[s][0].y);
+                    acc[s][1].x = fma(b, pr, acc[s][1].x);
+                    acc[s][1].y = fma(b, pim, acc[s][1].y);
+                }
+            }
+        }
+    }
+    cplx *pp = part + ((int64_t)f * nch + chunk) * 2 * NE;
+#pragma unroll
+    for (int s = 0; s < PSD_SLOTS; ++s) {
+        const int e = tid + 256 * s;
+        if (e < NE) {
+            pp[e] = acc[s][0];
+            pp[NE + e] = acc[s][1];
+        }
+    }
+    if (g == 0) {
+        sx = wave_sum(sx);
+        sn = wave_sum(sn);
+        if (tl == 0) {
+            msum[((int64_t)f * nch + chunk) * 2] = sx;
+            msum[((int64_t)f * nch + chunk) * 2 + 1] = sn;
+        }
+    }
+}
+
+__device__ __forceinline__ cplx c_div(cplx a, cplx b) {
+    // Smith's algorithm (what NumPy uses for complex division)
+    if (fabs(b.x) >= fabs(b.y)) {
+        if (b.x == 0.0 && b.y == 0.0) return c_make(a.x / fabs(b.x), a.y / fabs(b.x));
+        const double r = b.y / b.x, den = b.x + b.y * r;
+        return c_make((a.x + a.y * r) / den, (a.y - a.x * r) / den);
+    }
+    const double r = b.x / b.y, den = b.x * r + b.y;
+    return c_make((a.x * r + a.y) / den, (a.y * r - a.x) / den);
+}
+
+// Per frequency (one wave): Phi_X, Phi_N from the partial sums; Psi = solve(Phi_N,
+// Phi_X) by LU with partial pivoting, pseudo-inverse (lstsq) fallback on an exactly
+// singular Phi_N; W = Psi / max(Re tr Psi, eps); per-reference-channel SNR terms.
+__global__ __launch_bounds__(64) void mvdr_solve_kernel(
+    const cplx *__restrict__ part, const double *__restrict__ msum, int nch, int D, double eps,
+    cplx *__restrict__ Phi /* (F,2,D,D) */, cplx *__restrict__ W /* (F,D,D) */,
+    cplx *__restrict__ snr /* (F,D,2) */) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int m = D + (D & 1);
+    const int NE = tri_count(D);
+    const int W2 = 2 * D;
+    cplx *aug = reinterpret_cast<cplx *>(smem);   // D x 2D : [Phi_N | Phi_X] -> [U | Z] -> Psi
+    cplx *JA = aug + D * W2;                       // m * m
+    cplx *JV = JA + m * m;                         // m * m
+    JacobiScratch *js = reinterpret_cast<JacobiScratch *>(JV + m * m);
+    // flags live in the dynamic region too: a static __shared__ in front of it
+    // would break its 16-byte alignment
+    int *flags = reinterpret_cast<int *>(js + 1);
+    int &s_piv = flags[0];
+    int &s_singular = flags[1];
+    const int f = blockIdx.x, lane = threadIdx.x;
+
+    double sx = 0.0, sn = 0.0;
+    for (int c = 0; c < nch; ++c) {
+        sx += msum[((int64_t)f * nch + c) * 2];
+        sn += msum[((int64_t)f * nch + c) * 2 + 1];
+    }
+    const double dx = fmax(sx, 1e-10), dn = fmax(sn, 1e-10);
+    cplx *PhiX = Phi + (int64_t)f * 2 * D * D;
+    cplx *PhiN = PhiX + D * D;
+    for (int e = lane; e < NE; e += 64) {
+        // invert the packed index
+        int d1 = 0, rem = e;
+        while (rem >= D - d1) {
+            rem -= D - d1;
+            ++d1;
+        }
+        const int d2 = d1 + rem;
+        cplx vx = c_make(0.0, 0.0), vn = c_make(0.0, 0.0);
+        for (int c = 0; c < nch; ++c) {
+            const cplx *pp = part + ((int64_t)f * nch + c) * 2 * NE;
+            vx = c_add(vx, pp[e]);
+            vn = c_add(vn, pp[NE + e]);
+        }
+        vx = c_make(vx.x / dx, vx.y / dx);
+        vn = c_make(vn.x / dn, vn.y / dn);
+        if (d1 == d2) {
+            vx.y = 0.0;
+            vn.y = 0.0;
+        }
+        PhiX[d1 * D + d2] = vx;
+        PhiX[d2 * D + d1] = c_conj(vx);
+        PhiN[d1 * D + d2] = vn;
+        PhiN[d2 * D + d1] = c_conj(vn);
+        aug[d1 * W2 + d2] = vn;
+        aug[d2 * W2 + d1] = c_conj(vn);
+        aug[d1 * W2 + D + d2] = vx;
+        aug[d2 * W2 + D + d1] = c_conj(vx);
+    }
+    if (lane == 0) s_singular = 0;
+    __syncthreads();
+
+    // ---- LU with partial pivoting (pivot by |re| + |im| like LAPACK izamax)
+    for (int j = 0; j < D; ++j) {
+        double best = -1.0;
+        int bi = j;
+        if (lane >= j && lane < D) {
+            const cplx v = aug[lane * W2 + j];
+            best = fabs(v.x) + fabs(v.y);
+            bi = lane;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) {
+                best = ob;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            s_piv = bi;
+            if (!(best > 0.0)) s_singular = 1;   // zero or NaN pivot
+        }
+        __syncthreads();
+        if (s_singular) break;
+        const int p = s_piv;
+        if (p != j) {
+            for (int col = lane; col < W2; col += 64) {
+                const cplx t = aug[j * W2 + col];
+                aug[j * W2 + col] = aug[p * W2 + col];
+                aug[p * W2 + col] = t;
+            }
+        }
+        __syncthreads();
+        const cplx piv = aug[j * W2 + j];
+        const int rows = D - j - 1, cols = W2 - j - 1;
+        // multipliers first (column j), then the rank-1 update
+        for (int i = lane; i < rows; i += 64) {
+            const int r = j + 1 + i;
+            aug[r * W2 + j] = c_div(aug[r * W2 + j], piv);
+        }
+        __syncthreads();
+        for (int it = lane; it < rows * cols; it += 64) {
+            const int i = it / cols, cidx = it - i * cols;
+            const int r = j + 1 + i, col = j + 1 + cidx;
+            const cplx l = aug[r * W2 + j], u = aug[j * W2 + col];
+            cplx v = aug[r * W2 + col];
+            v.x -= l.x * u.x - l.y * u.y;
+            v.y -= l.x * u.y + l.y * u.x;
+            aug[r * W2 + col] = v;
+        }
+        __syncthreads();
+    }
+    const bool singular = s_singular != 0;
+    if (!singular) {
+        // back substitution U Psi = Z, one right-hand side per lane
+        if (lane < D) {
+            const int col = D + lane;
+            for (int j = D - 1; j >= 0; --j) {
+                cplx v = aug[j * W2 + col];
+                for (int k = j + 1; k < D; ++k) {
+                    const cplx u = aug[j * W2 + k], x = aug[k * W2 + col];
+                    v.x -= u.x * x.x - u.y * x.y;
+                    v.y -= u.x * x.y + u.y * x.x;
+                }
+                aug[j * W2 + col] = c_div(v, aug[j * W2 + j]);
+            }
+        }
+        __syncthreads();
+    } else {
+        // np.linalg.lstsq(Phi_N, Phi_X): minimum-norm solution via the Hermitian
+        // eigendecomposition; singular values below eps * D * max are dropped.
+        for (int idx = lane; idx < m * m; idx += 64) {
+            const int i = idx / m, jx = idx - i * m;
+            JA[idx] = (i < D && jx < D) ? PhiN[i * D + jx] : c_make(0.0, 0.0);
+        }
+        __syncthreads();
+        jacobi_eigh_wave(JA, JV, js, m, lane, 16);
+        double lmax = 0.0;
+        for (int i = lane; i < D; i += 64) lmax = fmax(lmax, fabs(JA[i * m + i].x));
+        lmax = wave_max(lmax);
+        const double cut = 2.220446049250313e-16 * (double)D * lmax;
+        // Psi = V diag(1/l) V^H Phi_X   (two small products through `aug`)
+        // step 1: tmp = V^H Phi_X  -> aug[:, 0:D]
+        for (int it = lane; it < D * D; it += 64) {
+            const int j = it / D, col = it - j * D;
+            cplx v = c_make(0.0, 0.0);
+            for (int i = 0; i < D; ++i) c_cfma(v, JV[i * m + j], PhiX[i * D + col]);
+            const double l = JA[j * m + j].x;
+            const double il = fabs(l) > cut ? 1.0 / l : 0.0;
+            aug[j * W2 + col] = c_scale(v, il);
+        }
+        __syncthreads();
+        for (int it = lane; it < D * D; it += 64) {
+            const int i = it / D, col = it - i * D;
+            cplx v = c_make(0.0, 0.0);
+            for (int j = 0; j < D; ++j) c_fma(v, JV[i * m + j], aug[j * W2 + col]);
+            aug[i * W2 + D + col] = v;
+        }
+        __syncthreads();
+    }
+    // Psi = aug[:, D:2D].  W = Psi / max(Re tr Psi, eps)
+    double tr = 0.0;
+    for (int i = lane; i < D; i += 64) tr += aug[i * W2 + D + i].x;
+    tr = wave_sum(tr);
+    const double dentr = fmax(tr, eps);
+    cplx *Wf = W + (int64_t)f * D * D;
+    for (int it = lane; it < D * D; it += 64) {
+        const int i = it / D, col = it - i * D;
+        const cplx v = aug[i * W2 + D + col];
+        const cplx wv = c_make(v.x / dentr, v.y / dentr);
+        aug[i * W2 + col] = wv;   // keep W in the left half for the SNR terms
+        Wf[it] = wv;
+    }
+    __syncthreads();
+    // SNR terms per reference channel r: w_r^H Phi_X w_r and w_r^H Phi_N w_r
+    if (lane < D) {
+        const int r = lane;
+        cplx num = c_make(0.0, 0.0), den = c_make(0.0, 0.0);
+        for (int d = 0; d < D; ++d) {
+            cplx tx = c_make(0.0, 0.0), tn = c_make(0.0, 0.0);
+            for (int e = 0; e < D; ++e) {
+                const cplx we = aug[e * W2 + r];
+                c_fma(tx, PhiX[d * D + e], we);
+                c_fma(tn, PhiN[d * D + e], we);
+            }
+            const cplx wd = aug[d * W2 + r];
+            c_cfma(num, wd, tx);
+            c_cfma(den, wd, tn);
+        }
+        snr[((int64_t)f * D + r) * 2] = num;
+        snr[((int64_t)f * D + r) * 2 + 1] = den;
+    }
+}
+
+// get_optimal_reference_channel: one reference channel for all frequencies.
+__global__ __launch_bounds__(64) void mvdr_ref_kernel(const cplx *__restrict__ snr, int F, int D,
+                                                      double eps, int32_t *__restrict__ ref) {
+    const int lane = threadIdx.x;
+    double val = -INFINITY;
+    bool isnan_ = false;
+    if (lane < D) {
+        cplx num = c_make(0.0, 0.0), den = c_make(0.0, 0.0);
+        for (int f = 0; f < F; ++f) {
+            num = c_add(num, snr[((int64_t)f * D + lane) * 2]);
+            den = c_add(den, snr[((int64_t)f * D + lane) * 2 + 1]);
+        }
+        // np.maximum(den, eps) on complex: lexicographic (real, then imag)
+        if (!(den.x > eps || (den.x == eps && den.y > 0.0))) den = c_make(eps, 0.0);
+        val = c_div(num, den).x;
+        isnan_ = val != val;
+    }
+    // np.argmax: first maximum, NaN counts as maximum
+    double best = val;
+    int bi = lane < D ? lane : 1 << 30;
+    bool bn = isnan_;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        const bool on = __shfl_xor((int)bn, o, 64) != 0;
+        bool take;
+        if (on != bn) take = on;
+        else if (on) take = oi < bi;
+        else take = ob > best || (ob == best && oi < bi);
+        if (take) {
+            best = ob;
+            bi = oi;
+            bn = on;
+        }
+    }
+    if (lane == 0) ref[0] = bi;
+}
+
+// w = W[:, ref] (optionally BAN-normalised), Xhat[t][f] = w^H y_t.  grid (chunks, F)
+__global__ __launch_bounds__(256) void mvdr_apply_kernel(
+    const cplx *__restrict__ Y, const cplx *__restrict__ W, const cplx *__restrict__ Phi,
+    const int32_t *__restrict__ ref, int F, int64_t T, int D, int ban, int chunk_frames,
+    cplx *__restrict__ Xhat, int32_t *__restrict__ ref_out) {
+    __shared__ cplx w[GSS_MAX_CHANNELS];
+    __shared__ cplx t1[GSS_MAX_CHANNELS];
+    __shared__ double s_norm;
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const int r = ref[0];
+    if (ref_out && blockIdx.x == 0 && f == 0 && tid == 0) ref_out[0] = r;
+    if (tid < D) w[tid] = W[((int64_t)f * D + tid) * D + r];
+    __syncthreads();
+    if (ban) {
+        const cplx *PhiN = Phi + ((int64_t)f * 2 + 1) * D * D;
+        if (tid < D) {
+            cplx v = c_make(0.0, 0.0);
+            for (int e = 0; e < D; ++e) c_fma(v, PhiN[tid * D + e], w[e]);
+            t1[tid] = v;   // Phi_N w
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // nominator = w^H Phi_N Phi_N w ; denominator = w^H Phi_N w
+            cplx nom = c_make(0.0, 0.0), den = c_make(0.0, 0.0);
+            for (int a = 0; a < D; ++a) {
+                cplx u = c_make(0.0, 0.0);   // (w^H Phi_N)_a = sum_d conj(w_d) Phi_N[d][a]
+                for (int d = 0; d < D; ++d) c_cfma(u, w[d], PhiN[d * D + a]);
+                c_fma(nom, u, t1[a]);
+                c_cfma(den, w[a], t1[a]);
+            }
+            const double n = sqrt(hypot(nom.x, nom.y));   // |sqrt(z)|
+            const double dd = hypot(den.x, den.y);
+            s_norm = n / dd;   // eps = 0 upstream: 0/0 -> NaN like the reference
+        }
+        __syncthreads();
+        if (tid < D) w[tid] = c_scale(w[tid], s_norm);
+        __syncthreads();
+    }
+    const int64_t c0 = (int64_t)blockIdx.x * chunk_frames;
+    const int64_t c1 = c0 + chunk_frames < T ? c0 + chunk_frames : T;
+    const cplx *Yf = Y + (int64_t)f * T * D;
+    for (int64_t t = c0 + tid; t < c1; t += blockDim.x) {
+        const cplx *y = Yf + t * D;
+        cplx v = c_make(0.0, 0.0);
+        for (int d = 0; d < D; ++d) c_cfma(v, w[d], y[d]);
+        Xhat[t * F + f] = v;
+    }
+}
+
+int psd_chunks(int F, int64_t T, int *chunk_frames) {
+    int64_t tiles = (T + PSD_TILE - 1) / PSD_TILE;
+    int64_t want = (2048 + F - 1) / F;
+    int64_t tpc = (tiles + want - 1) / want;
+    if (tpc < 1) tpc = 1;
+    *chunk_frames = (int)(tpc * PSD_TILE);
+    return (int)((tiles + tpc - 1) / tpc);
+}
+
+}  // namespace
+
+int masks_from_posteriors_run(gss_ctx *ctx, const double *gamma, int F, int K, int64_t T,
+                              int target, int drop, int64_t sf, int64_t ef, double *mx,
+                              double *mn) {
+    int64_t lo_end = 0, hi_begin = T;
+    if (drop) {
+        lo_end = sf >= 0 ? (sf < T ? sf : T) : (T + sf > 0 ? T + sf : 0);
+        if (ef > 0) hi_begin = T - ef > 0 ? T - ef : 0;
+    }
+    GSS_PROF(ctx, "masks");
+    const int64_t total = (int64_t)F * T;
+    hipLaunchKernelGGL(masks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       ctx->stream, gamma, F, K, T, target, lo_end, hi_begin, mx, mn);
+    GSS_LAUNCH_CHECK(ctx, "masks_kernel");
+    return GSS_OK;
+}
+
+size_t mvdr_workspace_bytes(int F, int64_t T, int D) {
+    const size_t NE = tri_count(D);
+    int cf;
+    const int nch = psd_chunks(F, T, &cf);
+    size_t b = 0;
+    b += align_up(sizeof(cplx) * (size_t)F * nch * 2 * NE);
+    b += align_up(sizeof(double) * (size_t)F * nch * 2);
+    b += align_up(sizeof(cplx) * (size_t)F * 2 * D * D);
+    b += align_up(sizeof(cplx) * (size_t)F * D * D);
+    b += align_up(sizeof(cplx) * (size_t)F * D * 2);
+    b += 256;
+    return b + 4096;
+}
+
+int mvdr_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double *mx,
+             const double *mn, int ban, cplx *Xhat, int32_t *ref_channel) {
+    const int NE = tri_count(D);
+    int cf;
+    const int nch = psd_chunks(F, T, &cf);
+    cplx *part = arena_alloc_t<cplx>(ctx, (size_t)F * nch * 2 * NE);
+    double *msum = arena_alloc_t<double>(ctx, (size_t)F * nch * 2);
+    cplx *Phi = arena_alloc_t<cplx>(ctx, (size_t)F * 2 * D * D);
+    cplx *W = arena_alloc_t<cplx>(ctx, (size_t)F * D * D);
+    cplx *snr = arena_alloc_t<cplx>(ctx, (size_t)F * D * 2);
+    int32_t *ref = arena_alloc_t<int32_t>(ctx, 4);
+    GSS_REQUIRE(ctx, part && msum && Phi && W && snr && ref, GSS_ERR_NOMEM, "mvdr workspace");
+    {
+        GSS_PROF(ctx, "psd");
+        const size_t lds = (sizeof(cplx) * (size_t)D * PSD_TS + sizeof(double) * 2 * PSD_TILE +
+                            2 * NE + 15) / 16 * 16;
+        hipLaunchKernelGGL(psd_kernel, dim3(nch, F), dim3(256), lds, ctx->stream, Y, mx, mn, T, D,
+                           NE, nch, cf, part, msum);
+        GSS_LAUNCH_CHECK(ctx, "psd_kernel");
+    }
+    {
+        GSS_PROF(ctx, "mvdr_solve");
+        const int m = D + (D & 1);
+        const size_t lds = (sizeof(cplx) * ((size_t)D * 2 * D + 2 * (size_t)m * m) +
+                            sizeof(JacobiScratch) + 16 + 15) / 16 * 16;
+        if (lds > 64 * 1024)
+            GSS_HIP_CHECK(ctx, hipFuncSetAttribute(
+                                   reinterpret_cast<const void *>(mvdr_solve_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(mvdr_solve_kernel, dim3(F), dim3(64), lds, ctx->stream, part, msum, nch,
+                           D, 1e-10, Phi, W, snr);
+        GSS_LAUNCH_CHECK(ctx, "mvdr_solve_kernel");
+    }
+    {
+        GSS_PROF(ctx, "mvdr_ref");
+        hipLaunchKernelGGL(mvdr_ref_kernel, dim3(1), dim3(64), 0, ctx->stream, snr, F, D, 1e-10,
+                           ref);
+        GSS_LAUNCH_CHECK(ctx, "mvdr_ref_kernel");
+    }
+    {
+        GSS_PROF(ctx, "mvdr_apply");
+        const int chunk = 1024;
+        hipLaunchKernelGGL(mvdr_apply_kernel, dim3((unsigned)((T + chunk - 1) / chunk), F),
+                           dim3(256), 0, ctx->stream, Y, W, Phi, ref, F, T, D, ban, chunk, Xhat,
+                           ref_channel);
+        GSS_LAUNCH_CHECK(ctx, "mvdr_apply_kernel");
+    }
+    return GSS_OK;
+}

@@ -1,0 +1,390 @@
+// STFT / iSTFT / frame-activity kernels and layout helpers.
+//
+// A1  nara_wpe.utils.stft   (reference call site core.py:305-312)
+// A9  nara_wpe.utils.istft  (core.py:314-321)
+// A5' activity_time_to_frequency (database/chime5/database.py:409-472)
+//
+// All three are HBM-bound streaming kernels (<1 % of the path's time).  The FFT
+// is a radix-2 decimation-in-time transform held in LDS; two real sequences
+// share one complex transform (two channels of a frame in the forward direction,
+// two frames in the inverse direction), which halves LDS traffic and lets one
+// workgroup write a contiguous run of channels of the (F,T,D) tensor.
+#include "gss_internal.h"
+
+namespace {
+
+constexpr int FFT_THREADS = 256;
+
+__device__ __forceinline__ unsigned bitrev(unsigned v, int bits) {
+    return __brev(v) >> (32 - bits);
+}
+
+// In-place radix-2 DIT over `nseq` sequences of length n (already bit-reversed)
+// stored back to back in LDS.  inverse: conjugated twiddles, no scaling.
+__device__ void fft_lds(cplx *s, int n, int log2n, int nseq, const cplx *tw, bool inverse) {
+    const int half_total = nseq * (n >> 1);
+    for (int stage = 0; stage < log2n; ++stage) {
+        const int half = 1 << stage;
+        const int tw_stride = n >> (stage + 1);
+        for (int b = threadIdx.x; b < half_total; b += blockDim.x) {
+            const int seq = b / (n >> 1);
+            const int i = b - seq * (n >> 1);
+            const int j = i & (half - 1);
+            const int base = ((i >> stage) << (stage + 1)) + j;
+            cplx w = tw[j * tw_stride];
+            if (inverse) w.y = -w.y;
+            cplx *p = s + seq * n + base;
+            const cplx a = p[0];
+            const cplx t = c_mul(p[half], w);
+            p[0] = c_add(a, t);
+            p[half] = c_sub(a, t);
+        }
+        __syncthreads();
+    }
+}
+
+// grid: (T, ceil(D / (2*PAIRS))); one workgroup transforms up to 2*PAIRS channels
+// of one frame.
+template <int PAIRS>
+__global__ __launch_bounds__(FFT_THREADS) void stft_kernel(
+    const double *__restrict__ x, int D, int64_t N, int64_t T, int size, int log2n, int shift,
+    int pad, const double *__restrict__ window, const cplx *__restrict__ twiddle,
+    cplx *__restrict__ Y) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx *s = reinterpret_cast<cplx *>(smem);            // PAIRS * size
+    cplx *tw = s + PAIRS * size;                          // size / 2
+    const int64_t t = blockIdx.x;
+    const int d0 = blockIdx.y * 2 * PAIRS;
+    const int F = size / 2 + 1;
+
+    for (int i = threadIdx.x; i < size / 2; i += blockDim.x) tw[i] = twiddle[i];
+    const int64_t n0 = t * shift - pad;
+    for (int idx = threadIdx.x; idx < PAIRS * size; idx += blockDim.x) {
+        const int pr = idx / size;
+        const int i = idx - pr * size;
+        const int64_t n = n0 + i;
+        const int da = d0 + 2 * pr, db = da + 1;
+        double va = 0.0, vb = 0.0;
+        if (n >= 0 && n < N) {
+            const double w = window[i];
+            if (da < D) va = x[(int64_t)da * N + n] * w;
+            if (db < D) vb = x[(int64_t)db * N + n] * w;
+        }
+        s[pr * size + bitrev(i, log2n)] = c_make(va, vb);
+    }
+    __syncthreads();
+    fft_lds(s, size, log2n, PAIRS, tw, false);
+
+    // Z = FFT(a + i b):  A[f] = (Z[f] + conj(Z[n-f])) / 2,  B[f] = (Z[f] - conj(Z[n-f])) / (2i)
+    const int nch = min(2 * PAIRS, D - d0);
+    for (int idx = threadIdx.x; idx < F * nch; idx += blockDim.x) {
+        const int f = idx / nch;
+        const int c = idx - f * nch;
+        const int pr = c >> 1;
+        const cplx z = s[pr * size + f];
+        const cplx zc = s[pr * size + ((size - f) & (size - 1))];
+        cplx v;
+        if ((c & 1) == 0) {
+            v = c_make(0.5 * (z.x + zc.x), 0.5 * (z.y - zc.y));
+        } else {
+            v = c_make(0.5 * (z.y + zc.y), 0.5 * (zc.x - z.x));
+        }
+        Y[((int64_t)f * T + t) * D + d0 + c] = v;
+    }
+}
+
+// Inverse: one workgroup handles frames 2*b and 2*b+1 of X (T,F) and writes
+// synthesis-windowed frames into frm (T, size).
+__global__ __launch_bounds__(FFT_THREADS) void istft_frames_kernel(
+    const cplx *__restrict__ X, int64_t T, int size, int log2n,
+    const double *__restrict__ syn, const cplx *__restrict__ twiddle,
+    double *__restrict__ frm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx *s = reinterpret_cast<cplx *>(smem);   // size
+    cplx *tw = s + size;                         // size / 2
+    const int F = size / 2 + 1;
+    const int64_t ta = (int64_t)blockIdx.x * 2, tb = ta + 1;
+    for (int i = threadIdx.x; i < size / 2; i += blockDim.x) tw[i] = twiddle[i];
+    // Hermitian extension of both spectra (irfft ignores Im of DC and Nyquist),
+    // Z = A + i B.
+    for (int k = threadIdx.x; k < size; k += blockDim.x) {
+        const int f = k <= size / 2 ? k : size - k;
+        cplx a = X[ta * F + f];
+        cplx b = tb < T ? X[tb * F + f] : c_make(0.0, 0.0);
+        if (f == 0 || f == size / 2) {
+            a.y = 0.0;
+            b.y = 0.0;
+        }
+        if (k > size / 2) {
+            a.y = -a.y;
+            b.y = -b.y;
+        }
+        s[bitrev(k, log2n)] = c_make(a.x - b.y, a.y + b.x);
+    }
+    __syncthreads();
+    fft_lds(s, size, log2n, 1, tw, true);
+    const double scale = 1.0 / (double)size;
+    for (int i = threadIdx.x; i < size; i += blockDim.x) {
+        const double w = syn[i];
+        frm[ta * size + i] = w * (s[i].x * scale);
+        if (tb < T) frm[tb * size + i] = w * (s[i].y * scale);
+    }
+}
+
+// Overlap-add in increasing frame order (np.add.at upstream), then drop the
+// fading pad.
+__global__ void istft_ola_kernel(const double *__restrict__ frm, int64_t T, int size, int shift,
+                                 int pad, int64_t n_out, double *__restrict__ out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_out) return;
+    const int64_t m = n + pad;
+    int64_t t_lo = m - size + 1;
+    t_lo = t_lo <= 0 ? 0 : (t_lo + shift - 1) / shift;
+    int64_t t_hi = m / shift;
+    if (t_hi > T - 1) t_hi = T - 1;
+    double acc = 0.0;
+    for (int64_t t = t_lo; t <= t_hi; ++t) acc += frm[t * size + (m - t * shift)];
+    out[n] = acc;
+}
+
+__global__ void activity_kernel(const uint8_t *__restrict__ act, int K, int64_t N, int64_t T,
+                                int size, int shift, int pad, uint8_t *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)K * T) return;
+    const int k = idx / T;
+    const int64_t t = idx - (int64_t)k * T;
+    int64_t a = t * shift - pad, b = a + size;
+    if (a < 0) a = 0;
+    if (b > N) b = N;
+    uint8_t any = 0;
+    const uint8_t *p = act + (int64_t)k * N;
+    for (int64_t n = a; n < b; ++n) any |= p[n];
+    out[idx] = any ? 1 : 0;
+}
+
+// (D,T,F) -> (F,T,D) and back, tiled through LDS so both sides are coalesced
+// along their fastest index.  Tile: 32 f x 32 d (t fixed per block.y).
+__global__ void dtf_to_ftd_kernel(const cplx *__restrict__ src, int D, int64_t T, int F,
+                                  cplx *__restrict__ dst) {
+    __shared__ cplx tile[32][33];
+    const int64_t t = blockIdx.y;
+    const int f0 = blockIdx.x * 32;
+    for (int d0 = 0; d0 < D; d0 += 32) {
+        for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+            const int d = d0 + r, f = f0 + threadIdx.x;
+            if (d < D && f < F) tile[r][threadIdx.x] = src[((int64_t)d * T + t) * F + f];
+        }
+        __syncthreads();
+        for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+            const int f = f0 + r, d = d0 + threadIdx.x;
+            if (d < D && f < F) dst[((int64_t)f * T + t) * D + d] = tile[threadIdx.x][r];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void ftd_to_dtf_kernel(const cplx *__restrict__ src, int F, int64_t T, int D,
+                                  cplx *__restrict__ dst) {
+    __shared__ cplx tile[32][33];
+    const int64_t t = blockIdx.y;
+    const int f0 = blockIdx.x * 32;
+    for (int d0 = 0; d0 < D; d0 += 32) {
+        for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+            const int f = f0 + r, d = d0 + threadIdx.x;
+            if (d < D && f < F) tile[r][threadIdx.x] = src[((int64_t)f * T + t) * D + d];
+        }
+        __syncthreads();
+        for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+            const int d = d0 + r, f = f0 + threadIdx.x;
+            if (d < D && f < F) dst[((int64_t)d * T + t) * F + f] = tile[threadIdx.x][r];
+        }
+        __syncthreads();
+    }
+}
+
+// dst[c][a] = src[a][c] for a in [0,A), c in [0,C), batched over `batch` slabs.
+__global__ void transpose_f64_kernel(const double *__restrict__ src, int64_t A, int64_t C,
+                                     double *__restrict__ dst) {
+    __shared__ double tile[32][33];
+    const int64_t a0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int64_t a = a0 + r, c = c0 + threadIdx.x;
+        if (a < A && c < C) tile[r][threadIdx.x] = src[a * C + c];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int64_t c = c0 + r, a = a0 + threadIdx.x;
+        if (a < A && c < C) dst[c * A + a] = tile[threadIdx.x][r];
+    }
+}
+
+// Beamformer types 'ch2' (Obs[2]) and 'sum' (core.py:259-262): Y (F,T,D) -> (T,F)
+__global__ void channel_pick_kernel(const cplx *__restrict__ Y, int F, int64_t T, int D,
+                                    int mode, cplx *__restrict__ Xhat) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)F * T) return;
+    const int f = idx / T;
+    const int64_t t = idx - (int64_t)f * T;
+    const cplx *y = Y + idx * D;
+    cplx v;
+    if (mode == 1) {
+        v = y[2];
+    } else {
+        v = c_make(0.0, 0.0);
+        for (int d = 0; d < D; ++d) v = c_add(v, y[d]);
+    }
+    Xhat[t * F + f] = v;
+}
+
+// postfilter 'mask_mul' (core.py:270-271): X_hat (T,F) *= target_mask (F,T)
+__global__ void mask_mul_kernel(cplx *__restrict__ Xhat, const double *__restrict__ mask, int F,
+                                int64_t T) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)F * T) return;
+    const int64_t t = idx / F;
+    const int f = idx - t * F;
+    const double m = mask[(int64_t)f * T + t];
+    Xhat[idx] = c_scale(Xhat[idx], m);
+}
+
+int ilog2(int n) {
+    int l = 0;
+    while ((1 << l) < n) ++l;
+    return l;
+}
+
+}  // namespace
+
+size_t stft_workspace_bytes(int64_t T, int size) {
+    return align_up(sizeof(double) * (size_t)(T + 1) * size) + 4096;
+}
+
+int stft_run(gss_ctx *ctx, const double *x, int D, int64_t N, int fading, cplx *Y) {
+    const int size = ctx->stft_size, shift = ctx->stft_shift;
+    const int64_t T = gss_stft_num_frames(N, size, shift, fading);
+    const int pad = fading ? size - shift : 0;
+    GSS_REQUIRE(ctx, T < 2147483647, GSS_ERR_UNSUPPORTED, "too many frames");
+    GSS_PROF(ctx, "stft");
+    // 4 pairs (8 channels) per workgroup while that fits comfortably in LDS
+    if (size <= 1024) {
+        constexpr int PAIRS = 4;
+        dim3 grid((unsigned)T, (D + 2 * PAIRS - 1) / (2 * PAIRS));
+        size_t lds = sizeof(cplx) * (PAIRS * size + size / 2);
+        hipLaunchKernelGGL(stft_kernel<PAIRS>, grid, dim3(FFT_THREADS), lds, ctx->stream, x, D, N,
+                           T, size, ilog2(size), shift, pad, ctx->win_analysis, ctx->twiddle, Y);
+    } else {
+        constexpr int PAIRS = 1;
+        dim3 grid((unsigned)T, (D + 1) / 2);
+        size_t lds = sizeof(cplx) * (PAIRS * size + size / 2);
+        hipLaunchKernelGGL(stft_kernel<PAIRS>, grid, dim3(FFT_THREADS), lds, ctx->stream, x, D, N,
+                           T, size, ilog2(size), shift, pad, ctx->win_analysis, ctx->twiddle, Y);
+    }
+    GSS_LAUNCH_CHECK(ctx, "stft_kernel");
+    return GSS_OK;
+}
+
+int istft_run(gss_ctx *ctx, const cplx *X, int64_t T, int fading, double *x) {
+    const int size = ctx->stft_size, shift = ctx->stft_shift;
+    const int pad = fading ? size - shift : 0;
+    const int64_t n_out = gss_istft_num_samples(T, size, shift, fading);
+    double *frm = arena_alloc_t<double>(ctx, (size_t)T * size);
+    GSS_REQUIRE(ctx, frm, GSS_ERR_NOMEM, "istft workspace");
+    {
+        GSS_PROF(ctx, "istft_frames");
+        size_t lds = sizeof(cplx) * (size + size / 2);
+        hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)((T + 1) / 2)), dim3(FFT_THREADS),
+                           lds, ctx->stream, X, T, size, ilog2(size), ctx->win_synthesis,
+                           ctx->twiddle, frm);
+        GSS_LAUNCH_CHECK(ctx, "istft_frames_kernel");
+    }
+    if (n_out > 0) {
+        GSS_PROF(ctx, "istft_ola");
+        hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0,
+                           ctx->stream, frm, T, size, shift, pad, n_out, x);
+        GSS_LAUNCH_CHECK(ctx, "istft_ola_kernel");
+    }
+    return GSS_OK;
+}
+
+int activity_run(gss_ctx *ctx, const uint8_t *act, int K, int64_t N, int fading, uint8_t *out) {
+    const int size = ctx->stft_size, shift = ctx->stft_shift;
+    const int64_t T = gss_stft_num_frames(N, size, shift, fading);
+    const int pad = fading ? size - shift : 0;
+    GSS_PROF(ctx, "activity");
+    const int64_t total = (int64_t)K * T;
+    hipLaunchKernelGGL(activity_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0,
+                       ctx->stream, act, K, N, T, size, shift, pad, out);
+    GSS_LAUNCH_CHECK(ctx, "activity_kernel");
+    return GSS_OK;
+}
+
+int channel_pick_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int mode,
+                     cplx *Xhat) {
+    GSS_PROF(ctx, "channel_pick");
+    const int64_t total = (int64_t)F * T;
+    hipLaunchKernelGGL(channel_pick_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       ctx->stream, Y, F, T, D, mode, Xhat);
+    GSS_LAUNCH_CHECK(ctx, "channel_pick_kernel");
+    return GSS_OK;
+}
+
+int mask_mul_run(gss_ctx *ctx, cplx *Xhat, const double *mask_ft, int F, int64_t T) {
+    GSS_PROF(ctx, "mask_mul");
+    const int64_t total = (int64_t)F * T;
+    hipLaunchKernelGGL(mask_mul_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       ctx->stream, Xhat, mask_ft, F, T);
+    GSS_LAUNCH_CHECK(ctx, "mask_mul_kernel");
+    return GSS_OK;
+}
+
+extern "C" int gss_layout_dtf_to_ftd(gss_ctx *ctx, const gss_cplx *src, int D, int64_t T, int F,
+                                     gss_cplx *dst) {
+    if (!ctx || !src || !dst) return GSS_ERR_INVALID;
+    GSS_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    GSS_REQUIRE(ctx, T <= 65535, GSS_ERR_UNSUPPORTED, "layout helper: T=%lld > 65535",
+                (long long)T);
+    hipLaunchKernelGGL(dtf_to_ftd_kernel, dim3((F + 31) / 32, (unsigned)T), dim3(32, 8), 0,
+                       ctx->stream, reinterpret_cast<const cplx *>(src), D, T, F,
+                       reinterpret_cast<cplx *>(dst));
+    GSS_LAUNCH_CHECK(ctx, "dtf_to_ftd_kernel");
+    return GSS_OK;
+}
+
+extern "C" int gss_layout_ftd_to_dtf(gss_ctx *ctx, const gss_cplx *src, int F, int64_t T, int D,
+                                     gss_cplx *dst) {
+    if (!ctx || !src || !dst) return GSS_ERR_INVALID;
+    GSS_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    GSS_REQUIRE(ctx, T <= 65535, GSS_ERR_UNSUPPORTED, "layout helper: T=%lld > 65535",
+                (long long)T);
+    hipLaunchKernelGGL(ftd_to_dtf_kernel, dim3((F + 31) / 32, (unsigned)T), dim3(32, 8), 0,
+                       ctx->stream, reinterpret_cast<const cplx *>(src), F, T, D,
+                       reinterpret_cast<cplx *>(dst));
+    GSS_LAUNCH_CHECK(ctx, "ftd_to_dtf_kernel");
+    return GSS_OK;
+}
+
+extern "C" int gss_layout_permute_f64(gss_ctx *ctx, const double *src, int64_t A, int64_t B,
+                                      int64_t C, int perm, double *dst) {
+    if (!ctx || !src || !dst) return GSS_ERR_INVALID;
+    GSS_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    // every supported permutation is a 2-D transpose of a (rows, cols) view
+    int64_t rows, cols;
+    if (perm == 0) {          // (A,B,C) -> (B,C,A): rows = A, cols = B*C
+        rows = A;
+        cols = B * C;
+    } else if (perm == 1) {   // (A,B,C) -> (C,A,B): rows = A*B, cols = C
+        rows = A * B;
+        cols = C;
+    } else if (perm == 2) {   // (A,B) -> (B,A)
+        rows = A;
+        cols = B;
+    } else {
+        return gss_fail(ctx, GSS_ERR_INVALID, "unknown permutation %d", perm);
+    }
+    GSS_REQUIRE(ctx, (rows + 31) / 32 <= 65535, GSS_ERR_UNSUPPORTED, "permute: too many rows");
+    hipLaunchKernelGGL(transpose_f64_kernel,
+                       dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32)),
+                       dim3(32, 8), 0, ctx->stream, src, rows, cols, dst);
+    GSS_LAUNCH_CHECK(ctx, "transpose_f64_kernel");
+    return GSS_OK;
+}

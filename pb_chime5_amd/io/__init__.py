@@ -1,0 +1,62 @@
+"""Minimal WAV in/out with the conventions of the reference's io layer
+(/root/reference/pb_chime5/io/audioread.py:34-226, io/audiowrite.py:16-207):
+
+* ``load_audio(path, start=None, stop=None)`` returns float64 in [-1, 1)
+  (PCM16 / 32768), shape (samples,) for mono and (channels, samples) otherwise;
+  lists / tuples / dicts of paths are loaded recursively and lists are stacked
+  into one array (the reference's ``recursive_load_decorator``).
+* ``dump_audio(obj, path)`` peak-normalises to (2**15 - 1) / 2**15 and writes
+  16-bit PCM at 16 kHz, like ``dump_audio(..., normalize=True, dtype=np.int16)``.
+
+The reference uses ``soundfile`` (absent in this image); only RIFF/WAVE PCM16 --
+what CHiME-5/6 ships -- is handled here, with the standard-library ``wave``.
+"""
+import wave
+from pathlib import Path
+
+import numpy as np
+
+
+def _load_one(path, start=None, stop=None):
+    with wave.open(str(path), 'rb') as w:
+        if w.getsampwidth() != 2:
+            raise NotImplementedError(
+                f'{path}: only 16-bit PCM is supported, got {8 * w.getsampwidth()} bit')
+        channels = w.getnchannels()
+        total = w.getnframes()
+        start = 0 if start is None else int(start)
+        stop = total if stop is None else min(int(stop), total)
+        w.setpos(min(start, total))
+        raw = w.readframes(max(stop - start, 0))
+    data = np.frombuffer(raw, dtype='<i2').astype(np.float64) / 2 ** 15
+    if channels == 1:
+        return data
+    return data.reshape(-1, channels).T
+
+
+def load_audio(path, start=None, stop=None):
+    if isinstance(path, dict):
+        return {k: load_audio(v, start=start, stop=stop) for k, v in path.items()}
+    if isinstance(path, (list, tuple)):
+        return np.array([load_audio(p, start=start, stop=stop) for p in path])
+    return _load_one(path, start=start, stop=stop)
+
+
+def dump_audio(obj, path, *, sample_rate=16000, normalize=True):
+    obj = np.asarray(obj)
+    if normalize:
+        if obj.dtype.kind not in 'fi':
+            raise TypeError(f'Only float and int is supported with normalize, got {obj.dtype}')
+        correction = (2 ** 15 - 1) / (2 ** 15)
+        obj = obj * (correction / np.amax(np.abs(obj)))
+    if obj.dtype.kind == 'f':
+        pcm = np.clip(np.rint(obj * 2 ** 15), -2 ** 15, 2 ** 15 - 1).astype('<i2')
+    else:
+        pcm = obj.astype('<i2')
+    channels = 1 if pcm.ndim == 1 else pcm.shape[0]
+    Path(path).parent.mkdir(parents=True, exist_ok=True)
+    with wave.open(str(path), 'wb') as w:
+        w.setnchannels(channels)
+        w.setsampwidth(2)
+        w.setframerate(sample_rate)
+        w.writeframes(np.ascontiguousarray(pcm.T).tobytes())

@@ -1,0 +1,116 @@
+"""Sparse boolean vector kept as a sorted list of half-open intervals, with the
+slice semantics the hot path needs (``arr[start:stop] -> dense bool`` at
+/root/reference/pb_chime5/core.py:422-425).  Same public behaviour as the
+reference's ``ArrayIntervall`` (pb_chime5/utils/intervall_array.py:103-455; its
+Cython helpers ``cy_intersection`` / ``cy_non_intersection`` /
+``cy_str_to_intervalls`` in utils/intervall_array_util.pyx are plain integer
+interval arithmetic and are done inline here).  Integer-exact.
+"""
+import numpy as np
+
+
+def _normalize(intervals):
+    """Sort, drop empties, merge touching / overlapping intervals."""
+    out = []
+    for s, e in sorted((int(s), int(e)) for s, e in intervals if s < e):
+        if out and s <= out[-1][1]:
+            if e > out[-1][1]:
+                out[-1] = (out[-1][0], e)
+        else:
+            out.append((s, e))
+    return tuple(out)
+
+
+class ArrayIntervall:
+    def __init__(self, shape):
+        if isinstance(shape, (int, np.integer)):
+            shape = [int(shape)]
+        if shape is not None:
+            assert len(shape) == 1, shape
+            shape = tuple(shape)
+        self.shape = shape
+        self._intervals = ()
+
+    # ---- construction --------------------------------------------------
+    @staticmethod
+    def from_str(string, shape):
+        """``'1:4, 5:20'`` -> intervals."""
+        ai = ArrayIntervall(shape)
+        pairs = []
+        for item in string.split(','):
+            item = item.strip()
+            if item:
+                s, e = item.split(':')
+                pairs.append((int(s), int(e)))
+        ai._intervals = _normalize(pairs)
+        return ai
+
+    @staticmethod
+    def from_array(array):
+        array = np.asarray(array)
+        assert array.ndim == 1, (array.ndim, array)
+        assert array.dtype == bool, array.dtype
+        edges = np.diff(np.concatenate([[0], array.astype(np.int8), [0]]))
+        ai = ArrayIntervall(shape=array.shape)
+        ai._intervals = tuple(zip(np.flatnonzero(edges > 0).tolist(),
+                                  np.flatnonzero(edges < 0).tolist()))
+        return ai
+
+    def __reduce__(self):
+        return self.from_str, (self._intervals_as_str, self.shape[-1])
+
+    # ---- views ---------------------------------------------------------
+    def __len__(self):
+        return self.shape[0]
+
+    @property
+    def normalized_intervals(self):
+        return self._intervals
+
+    intervals = normalized_intervals
+
+    @property
+    def _intervals_as_str(self):
+        return ', '.join(f'{s}:{e}' for s, e in self._intervals)
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}("{self._intervals_as_str}", shape={self.shape})'
+
+    def _parse_item(self, item):
+        assert isinstance(item, slice), (type(item), item)
+        assert item.step is None, item
+        start = 0 if item.start is None else item.start
+        stop = self.shape[-1] if item.stop is None else item.stop
+        for v in (start, stop):
+            assert v >= 0, (v, item)
+            if self.shape is not None:
+                assert v <= self.shape[-1], (v, item)
+        return int(start), int(stop)
+
+    # ---- mutation ------------------------------------------------------
+    def __setitem__(self, item, value):
+        start, stop = self._parse_item(item)
+        if np.isscalar(value) and value == 1:
+            self._intervals = _normalize(self._intervals + ((start, stop),))
+        elif isinstance(value, (tuple, list, np.ndarray)):
+            assert len(value) == stop - start, (start, stop, len(value))
+            inner = ArrayIntervall.from_array(np.asarray(value, dtype=bool))._intervals
+            kept = []
+            for s, e in self._intervals:      # remove [start, stop) from what is there
+                if s < start:
+                    kept.append((s, min(e, start)))
+                if e > stop:
+                    kept.append((max(s, stop), e))
+            self._intervals = _normalize(
+                kept + [(s + start, e + start) for s, e in inner])
+        else:
+            raise NotImplementedError(value)
+
+    def __getitem__(self, item):
+        start, stop = self._parse_item(item)
+        arr = np.zeros(stop - start, dtype=bool)
+        for s, e in self._intervals:
+            s, e = max(s, start), min(e, stop)
+            if s < e:
+                arr[s - start:e - start] = True
+        return arr

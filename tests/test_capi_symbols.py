@@ -1,0 +1,65 @@
+"""The C-ABI library loads without a GPU and exports every symbol that
+include/gss_hip.h declares (no compute calls here)."""
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+def _declared_functions():
+    text = (REPO / 'include' / 'gss_hip.h').read_text()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(gss_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from pb_chime5_amd import build, _capi
+    build.build(verbose=False)
+    lib = _capi.load_library()
+    names = _declared_functions()
+    assert len(names) >= 25, names
+    for name in names:
+        assert hasattr(lib, name), f'{name} is declared in gss_hip.h but not exported'
+    # the ctypes prototypes cover exactly the declared functions
+    assert sorted(_capi.SIGNATURES) == names
+    assert b'gfx950' in lib.gss_version()
+
+
+def test_geometry_helpers_match_oracle():
+    import gss_oracle as oracle
+    from pb_chime5_amd import ops
+    for size, shift in ((1024, 256), (512, 128), (64, 16), (4, 2)):
+        for fading in (True, False):
+            for n in (0, 1, 5, 255, 256, 257, 1000, 1024, 1025, 5000, 80000, 240000):
+                assert ops.stft_frames(n, size, shift, fading) == \
+                    oracle.stft(__import__('numpy').zeros(n), size, shift, fading=fading,
+                                window=__import__('numpy').ones(size)).shape[0], (size, shift, fading, n)
+            for s in (0, 1, 255, 256, 257, 16000, 240000):
+                assert ops.samples_to_stft_frames(s, size, shift, fading=fading) == \
+                    oracle.samples_to_stft_frames(s, size, shift, fading=fading)
+
+
+def test_no_gpu_means_loud_failure():
+    """The product path must not fall back to anything when no GPU is present."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from pb_chime5_amd import _capi
+    with pytest.raises(_capi.GssError):
+        _capi.Context(0)
+
+
+def test_product_does_not_import_oracle():
+    import ast
+    pkg = REPO / 'pb_chime5_amd'
+    for path in pkg.rglob('*.py'):
+        tree = ast.parse(path.read_text())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or '']
+            for n in names:
+                assert 'oracle' not in n, (path, n)

