@@ -183,7 +183,7 @@ typedef struct {
  * (core.py:85-86,210-212,275-276,568-569). */
 typedef struct {
     gss_cplx *Obs_ftd;        /* (F,T,D) after WPE                             */
-    uint8_t *act_frames;      /* (K,T)                                         */
+    uint8_t *act_frames;      /* (K,T), the first T frames of the activity     */
     double *gamma;            /* (F,K,T) posteriors before context zeroing     */
     double *target_mask;      /* (F,T)                                         */
     double *distortion_mask;  /* (F,T)                                         */
@@ -192,13 +192,17 @@ typedef struct {
 } gss_debug_taps;
 
 /* A0  Enhancer.enhance_observation (core.py:514-571), all intermediates kept in
- * HBM.  obs (D,N) double, act (K,N) uint8 in dict order, target_index = position
- * of speaker_id among the activity keys; start/end_context_samples as computed by
+ * HBM.  obs (D,N) double, act (K,N_act) uint8 in dict order with N_act >= N
+ * samples (the reference slices the activity of the reference array, which may be
+ * longer than the common length the arrays were cut to, and uses its first T
+ * frames: core.py:177-184), target_index = position of speaker_id among the
+ * activity keys; start/end_context_samples as computed by
  * start_end_context_frames (core.py:217-222).  out receives
  * gss_istft_num_samples(T,...) samples. */
 int gss_enhance_observation(gss_ctx *ctx, const gss_params *params,
                             const double *obs_dev, int D, int64_t N,
-                            const uint8_t *act_dev, int K, int target_index,
+                            const uint8_t *act_dev, int K, int64_t N_act,
+                            int target_index,
                             int64_t start_context_samples,
                             int64_t end_context_samples,
                             double *out_dev, const gss_debug_taps *taps);
@@ -206,7 +210,8 @@ int gss_enhance_observation(gss_ctx *ctx, const gss_params *params,
 /* Same, with host buffers: copies in, runs, copies out, synchronises. */
 int gss_enhance_observation_host(gss_ctx *ctx, const gss_params *params,
                                  const double *obs_host, int D, int64_t N,
-                                 const uint8_t *act_host, int K, int target_index,
+                                 const uint8_t *act_host, int K, int64_t N_act,
+                                 int target_index,
                                  int64_t start_context_samples,
                                  int64_t end_context_samples,
                                  double *out_host);

@@ -79,11 +79,11 @@ SIGNATURES = {
                                        c_int64, c_int, c_void_p]),
     'gss_enhance_observation': (
         c_int, [c_void_p, ctypes.POINTER(GssParams), c_void_p, c_int, c_int64,
-                c_void_p, c_int, c_int, c_int64, c_int64, c_void_p,
+                c_void_p, c_int, c_int64, c_int, c_int64, c_int64, c_void_p,
                 ctypes.POINTER(GssDebugTaps)]),
     'gss_enhance_observation_host': (
         c_int, [c_void_p, ctypes.POINTER(GssParams), c_void_p, c_int, c_int64,
-                c_void_p, c_int, c_int, c_int64, c_int64, c_void_p]),
+                c_void_p, c_int, c_int64, c_int, c_int64, c_int64, c_void_p]),
     'gss_workspace_bytes': (c_size_t, [c_void_p]),
     'gss_selftest_mfma': (c_int, [c_void_p]),
 }

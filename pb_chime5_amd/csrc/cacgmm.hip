@@ -29,7 +29,8 @@ enum { MODE_FIRST = 0, MODE_EM = 1, MODE_PREDICT = 2 };
 
 struct EmArgs {
     const cplx *Y;          // (F,T,D)
-    const uint8_t *act;     // (K,T)
+    const uint8_t *act;     // (K,act_stride), first T columns used
+    int64_t act_stride;
     const cplx *Mq;         // (F,NE,K)
     const double *logdet;   // (F,K)
     const double *pi;       // (F,K)
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void em_step_kernel(EmArgs a) {
                 double s = 0.0;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const double v = (valid && a.act[(int64_t)k * T + t]) ? 1.0 : 1e-10;
+                    const double v = (valid && a.act[(int64_t)k * a.act_stride + t]) ? 1.0 : 1e-10;
                     gam[k] = v;
                     s += v;
                 }
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void em_step_kernel(EmArgs a) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     double v = exp(lp[k] - mx) * pis[k];
-                    if (a.masked) v *= (valid && a.act[(int64_t)k * T + t]) ? 1.0 : 0.0;
+                    if (a.masked) v *= (valid && a.act[(int64_t)k * a.act_stride + t]) ? 1.0 : 0.0;
                     gam[k] = v;
                     s += v;
                 }
@@ -394,12 +395,14 @@ size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K) {
     return b + 4096;
 }
 
-int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8_t *act, int K,
+int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8_t *act,
+               int64_t act_stride, int K,
                int iterations, int iterations_post, double *gamma) {
     const int NE = tri_count(D);
     EmArgs a{};
     a.Y = Y;
     a.act = act;
+    a.act_stride = act_stride;
     a.T = T;
     a.D = D;
     a.NE = NE;

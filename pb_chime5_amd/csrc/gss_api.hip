@@ -373,7 +373,7 @@ extern "C" int gss_cacgmm(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T, int
                 "gss_cacgmm: bad arguments");
     GSS_TRY(check_cacgmm_args(ctx, D, K, iterations, post));
     GSS_TRY(arena_reserve(ctx, cacgmm_workspace_bytes(F, T, D, K)));
-    return cacgmm_run(ctx, reinterpret_cast<const cplx *>(Y), F, T, D, act, K, iterations,
+    return cacgmm_run(ctx, reinterpret_cast<const cplx *>(Y), F, T, D, act, T, K, iterations,
                       post, gamma);
 }
 
@@ -418,11 +418,12 @@ static int check_params(gss_ctx *ctx, const gss_params *p) {
     return GSS_OK;
 }
 
-static size_t pipeline_workspace(const gss_params *p, int F, int64_t T, int D, int K) {
+static size_t pipeline_workspace(const gss_params *p, int F, int64_t T, int64_t T_act, int D,
+                                 int K) {
     size_t b = 0;
     size_t ftd = align_up(sizeof(cplx) * (size_t)F * T * D);
     b += 2 * ftd;                                            // Y, X
-    b += align_up((size_t)K * T);                            // frame activity
+    b += align_up((size_t)K * T_act);                        // frame activity
     b += align_up(sizeof(double) * (size_t)F * K * T);       // gamma
     b += 2 * align_up(sizeof(double) * (size_t)F * T);       // masks
     b += align_up(sizeof(cplx) * (size_t)F * T);             // Xhat
@@ -437,8 +438,9 @@ static size_t pipeline_workspace(const gss_params *p, int F, int64_t T, int D, i
 
 extern "C" int gss_enhance_observation(gss_ctx *ctx, const gss_params *p, const double *obs,
                                        int D, int64_t N, const uint8_t *act, int K,
-                                       int target, int64_t start_ctx, int64_t end_ctx,
-                                       double *out, const gss_debug_taps *taps) {
+                                       int64_t N_act, int target, int64_t start_ctx,
+                                       int64_t end_ctx, double *out,
+                                       const gss_debug_taps *taps) {
     GSS_ENTER(ctx);
     GSS_TRY(check_windows(ctx));
     GSS_TRY(check_params(ctx, p));
@@ -460,11 +462,17 @@ extern "C" int gss_enhance_observation(gss_ctx *ctx, const gss_params *p, const 
     const int size = p->stft_size, shift = p->stft_shift, fading = p->stft_fading;
     const int F = size / 2 + 1;
     const int64_t T = gss_stft_num_frames(N, size, shift, fading);
+    const int64_t T_act = gss_stft_num_frames(N_act, size, shift, fading);
+    // GSS.__call__ uses initialization[..., :T]: fewer activity frames than STFT
+    // frames is a shape error in the reference too
+    GSS_REQUIRE(ctx, T_act >= T, GSS_ERR_INVALID,
+                "activity covers %lld frames but the observation has %lld",
+                (long long)T_act, (long long)T);
 
-    GSS_TRY(arena_reserve(ctx, pipeline_workspace(p, F, T, D, K)));
+    GSS_TRY(arena_reserve(ctx, pipeline_workspace(p, F, T, T_act, D, K)));
     cplx *Y = arena_alloc_t<cplx>(ctx, (size_t)F * T * D);
     cplx *X = p->wpe ? arena_alloc_t<cplx>(ctx, (size_t)F * T * D) : Y;
-    uint8_t *actf = arena_alloc_t<uint8_t>(ctx, (size_t)K * T);
+    uint8_t *actf = arena_alloc_t<uint8_t>(ctx, (size_t)K * T_act);
     double *gamma = arena_alloc_t<double>(ctx, (size_t)F * K * T);
     double *mx = arena_alloc_t<double>(ctx, (size_t)F * T);
     double *mn = arena_alloc_t<double>(ctx, (size_t)F * T);
@@ -479,8 +487,8 @@ extern "C" int gss_enhance_observation(gss_ctx *ctx, const gss_params *p, const 
         GSS_TRY(wpe_run(ctx, Y, F, T, D, p->wpe_taps, p->wpe_delay, p->wpe_iterations, X));
         ctx->arena_off = mark;
     }
-    GSS_TRY(activity_run(ctx, act, K, N, fading, actf));
-    GSS_TRY(cacgmm_run(ctx, X, F, T, D, actf, K, p->bss_iterations, p->bss_iterations_post,
+    GSS_TRY(activity_run(ctx, act, K, N_act, fading, actf));
+    GSS_TRY(cacgmm_run(ctx, X, F, T, D, actf, T_act, K, p->bss_iterations, p->bss_iterations_post,
                        gamma));
     ctx->arena_off = mark;
 
@@ -508,7 +516,10 @@ extern "C" int gss_enhance_observation(gss_ctx *ctx, const gss_params *p, const 
             return GSS_OK;
         };
         GSS_TRY(cp(taps->Obs_ftd, X, sizeof(cplx) * (size_t)F * T * D));
-        GSS_TRY(cp(taps->act_frames, actf, (size_t)K * T));
+        if (taps->act_frames)
+            GSS_HIP_CHECK(ctx, hipMemcpy2DAsync(taps->act_frames, (size_t)T, actf, (size_t)T_act,
+                                                (size_t)T, (size_t)K, hipMemcpyDeviceToDevice,
+                                                ctx->stream));
         GSS_TRY(cp(taps->gamma, gamma, sizeof(double) * (size_t)F * K * T));
         GSS_TRY(cp(taps->target_mask, mx, sizeof(double) * (size_t)F * T));
         GSS_TRY(cp(taps->distortion_mask, mn, sizeof(double) * (size_t)F * T));
@@ -520,8 +531,9 @@ extern "C" int gss_enhance_observation(gss_ctx *ctx, const gss_params *p, const 
 
 extern "C" int gss_enhance_observation_host(gss_ctx *ctx, const gss_params *p,
                                             const double *obs, int D, int64_t N,
-                                            const uint8_t *act, int K, int target,
-                                            int64_t start_ctx, int64_t end_ctx, double *out) {
+                                            const uint8_t *act, int K, int64_t N_act,
+                                            int target, int64_t start_ctx, int64_t end_ctx,
+                                            double *out) {
     GSS_ENTER(ctx);
     GSS_REQUIRE(ctx, p && obs && act && out && N >= 1 && D >= 1 && K >= 1, GSS_ERR_INVALID,
                 "gss_enhance_observation_host: bad arguments");
@@ -530,13 +542,13 @@ extern "C" int gss_enhance_observation_host(gss_ctx *ctx, const gss_params *p,
     double *obs_d = nullptr, *out_d = nullptr;
     uint8_t *act_d = nullptr;
     int st = gss_dev_malloc(ctx, sizeof(double) * (size_t)D * N, (void **)&obs_d);
-    if (st == GSS_OK) st = gss_dev_malloc(ctx, (size_t)K * N, (void **)&act_d);
+    if (st == GSS_OK) st = gss_dev_malloc(ctx, (size_t)K * N_act, (void **)&act_d);
     if (st == GSS_OK) st = gss_dev_malloc(ctx, sizeof(double) * (size_t)n_out, (void **)&out_d);
     if (st == GSS_OK) st = gss_memcpy_h2d(ctx, obs_d, obs, sizeof(double) * (size_t)D * N);
-    if (st == GSS_OK) st = gss_memcpy_h2d(ctx, act_d, act, (size_t)K * N);
+    if (st == GSS_OK) st = gss_memcpy_h2d(ctx, act_d, act, (size_t)K * N_act);
     if (st == GSS_OK)
-        st = gss_enhance_observation(ctx, p, obs_d, D, N, act_d, K, target, start_ctx, end_ctx,
-                                     out_d, nullptr);
+        st = gss_enhance_observation(ctx, p, obs_d, D, N, act_d, K, N_act, target, start_ctx,
+                                     end_ctx, out_d, nullptr);
     if (st == GSS_OK) st = gss_memcpy_d2h(ctx, out, out_d, sizeof(double) * (size_t)n_out);
     std::string keep = ctx->error;
     (void)hipStreamSynchronize(ctx->stream);

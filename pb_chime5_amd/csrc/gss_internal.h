@@ -161,7 +161,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
 
 size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K);
 int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8_t *act,
-               int K, int iterations, int iterations_post, double *gamma);
+               int64_t act_stride, int K, int iterations, int iterations_post, double *gamma);
 
 size_t mvdr_workspace_bytes(int F, int64_t T, int D);
 int mvdr_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double *mx,

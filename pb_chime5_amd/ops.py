@@ -258,7 +258,7 @@ class ResidentUtterance:
         self.ctx = ctx
         self.D, self.N = obs.shape
         self.K = act.shape[0]
-        assert act.shape[1] == self.N, (act.shape, obs.shape)
+        self.N_act = act.shape[1]
         self.params = params
         self.T = stft_frames(self.N, params.stft_size, params.stft_shift,
                              params.stft_fading)
@@ -272,7 +272,7 @@ class ResidentUtterance:
         ctx = self.ctx
         ctx._check(ctx.lib.gss_enhance_observation(
             ctx.handle, ctypes.byref(self.params), c_void_p(self.obs_d.ptr), self.D,
-            self.N, c_void_p(self.act_d.ptr), self.K, int(target_index),
+            self.N, c_void_p(self.act_d.ptr), self.K, self.N_act, int(target_index),
             int(start_context), int(end_context), c_void_p(self.out_d.ptr),
             ctypes.byref(taps) if taps is not None else None),
             'gss_enhance_observation')

@@ -24,6 +24,8 @@ def rel_err(a, b):
     a = np.asarray(a)
     b = np.asarray(b)
     assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size == 0:
+        return 0.0
     scale = np.max(np.abs(b))
     if scale == 0:
         return float(np.max(np.abs(a)))
