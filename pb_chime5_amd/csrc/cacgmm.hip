@@ -17,6 +17,8 @@
 // where Mq holds B_k^-1 with the off-diagonals doubled.  That is 4 real FMAs per
 // (entry, class, frame) instead of 12 for the dense form.
 #include "gss_internal.h"
+#include <cstdlib>
+
 #include "jacobi.h"
 
 namespace {
@@ -249,20 +251,60 @@ __global__ __launch_bounds__(256) void em_step_kernel(EmArgs a) {
     }
 }
 
-// grid (K, F), block 64 (one wave per class matrix)
+// In-place lower Cholesky of the Hermitian positive definite n x n matrix A (LDS,
+// leading dimension ld) by one wave; returns false (wave-uniform) on a
+// non-positive pivot.  Only the lower triangle is referenced / written.
+__device__ inline bool cholesky_lower_wave(cplx *A, int n, int ld, int lane) {
+    for (int j = 0; j < n; ++j) {
+        const double ajj = A[j * ld + j].x;
+        if (!(ajj > 0.0) || !isfinite(ajj)) return false;
+        const double d = sqrt(ajj), dinv = 1.0 / d;
+        __syncthreads();
+        for (int i = j + lane; i < n; i += 64) {
+            if (i == j) A[j * ld + j] = c_make(d, 0.0);
+            else A[i * ld + j] = c_scale(A[i * ld + j], dinv);
+        }
+        __syncthreads();
+        // trailing update of the lower triangle: A[i][k] -= L[i][j] conj(L[k][j]), j < k <= i
+        const int r = n - j - 1;
+        for (int it = lane; it < r * r; it += 64) {
+            const int ii = it / r, kk = it - ii * r;
+            if (kk > ii) continue;
+            const int i = j + 1 + ii, k = j + 1 + kk;
+            const cplx li = A[i * ld + j], lk = A[k * ld + j];
+            cplx v = A[i * ld + k];
+            v.x -= li.x * lk.x + li.y * lk.y;
+            v.y -= li.y * lk.x - li.x * lk.y;
+            A[i * ld + k] = v;
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
+// grid (K, F), block 64 (one wave per class matrix).
+//
+// The reference keeps (V, lambda) with lambda <- max(lambda / lambda_max, 1e-10) and
+// evaluates q = y^H V diag(1/lambda) V^H y and ln det = sum ln lambda.  A per-class
+// scale of lambda cancels between -D ln q and -ln det, and rescales the next
+// covariance by a constant that the next normalisation removes again.  So whenever
+// NO eigenvalue is floored -- lambda_min > 1e-10 lambda_max, certified here by a
+// successful Cholesky factorisation of B - 1e-10 tr(B) I (tr B >= lambda_max) --
+// B^-1 and ln det B from a Cholesky factorisation give the same posteriors, and
+// the eigendecomposition is only run for matrices that fail the certificate.
 __global__ __launch_bounds__(64) void em_eig_kernel(const cplx *__restrict__ Bp,
                                                     const double *__restrict__ Sg, int nch, int D,
                                                     int K, int64_t T, double eig_floor,
-                                                    cplx *__restrict__ Mq,
+                                                    int force_eigh, cplx *__restrict__ Mq,
                                                     double *__restrict__ logdet,
-                                                    double *__restrict__ pi) {
+                                                    double *__restrict__ pi,
+                                                    int *__restrict__ slow_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = D + (D & 1);
     const int NE = tri_count(D);
     cplx *A = reinterpret_cast<cplx *>(smem);   // m * m
     cplx *V = A + m * m;                         // m * m
     double *lam = reinterpret_cast<double *>(V + m * m);   // m
-    JacobiScratch *js = reinterpret_cast<JacobiScratch *>(lam + m);
     const int k = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
 
     double sg = 0.0;
@@ -271,35 +313,110 @@ __global__ __launch_bounds__(64) void em_eig_kernel(const cplx *__restrict__ Bp,
 
     for (int idx = lane; idx < m * m; idx += 64) A[idx] = c_make(0.0, 0.0);
     __syncthreads();
-    for (int d1 = 0; d1 < D; ++d1)
-        for (int d2 = d1 + lane; d2 < D; d2 += 64) {
-            const int e = tri_index(d1, d2, D);
-            cplx v = c_make(0.0, 0.0);
-            for (int c = 0; c < nch; ++c)
-                v = c_add(v, Bp[(((int64_t)f * nch + c) * K + k) * NE + e]);
-            v.x = ((double)D * v.x) / den;
-            v.y = ((double)D * v.y) / den;
-            if (d1 == d2) v.y = 0.0;
-            A[d1 * m + d2] = v;
-            A[d2 * m + d1] = c_conj(v);
+    double tr = 0.0;
+    for (int e = lane; e < NE; e += 64) {
+        int d1 = 0, rem = e;
+        while (rem >= D - d1) {
+            rem -= D - d1;
+            ++d1;
         }
-    __syncthreads();
-    jacobi_eigh_wave(A, V, js, m, lane, 16);
-
-    double lmax = -INFINITY;
-    for (int i = lane; i < D; i += 64) lmax = fmax(lmax, A[i * m + i].x);
-    lmax = wave_max(lmax);
-    double ld = 0.0;
-    for (int i = lane; i < D; i += 64) {
-        double l = A[i * m + i].x / fmax(lmax, GSS_TINY);
-        l = fmax(l, eig_floor);
-        lam[i] = 1.0 / l;
-        ld += log(l);
+        const int d2 = d1 + rem;
+        cplx v = c_make(0.0, 0.0);
+        for (int c = 0; c < nch; ++c)
+            v = c_add(v, Bp[(((int64_t)f * nch + c) * K + k) * NE + e]);
+        v.x = ((double)D * v.x) / den;
+        v.y = ((double)D * v.y) / den;
+        if (d1 == d2) {
+            v.y = 0.0;
+            tr += v.x;
+        }
+        A[d1 * m + d2] = v;
+        A[d2 * m + d1] = c_conj(v);
     }
-    ld = wave_sum(ld);
+    tr = wave_sum(tr);
     __syncthreads();
-    for (int d1 = 0; d1 < D; ++d1)
-        for (int d2 = d1 + lane; d2 < D; d2 += 64) {
+
+    bool fast = false;
+    if (!force_eigh && tr > 0.0 && isfinite(tr)) {
+        // certificate: B - floor * tr(B) * I positive definite  (work in V)
+        const double shift = eig_floor * tr;
+        for (int idx = lane; idx < D * D; idx += 64) {
+            const int i = idx / D, j = idx - i * D;
+            cplx v = A[i * m + j];
+            if (i == j) v.x -= shift;
+            V[i * m + j] = v;
+        }
+        __syncthreads();
+        fast = cholesky_lower_wave(V, D, m, lane);
+        __syncthreads();
+    }
+    if (fast) {
+        // factor B itself (it is positive definite a fortiori)
+        for (int idx = lane; idx < D * D; idx += 64) {
+            const int i = idx / D, j = idx - i * D;
+            V[i * m + j] = A[i * m + j];
+        }
+        __syncthreads();
+        fast = cholesky_lower_wave(V, D, m, lane);
+        __syncthreads();
+    }
+    double ld = 0.0;
+    if (fast) {
+        // ln det B = 2 sum ln L_ii ;  Linv = L^-1 (lower), one column per lane, into A
+        for (int i = lane; i < D; i += 64) ld += 2.0 * log(V[i * m + i].x);
+        ld = wave_sum(ld);
+        __syncthreads();
+        if (lane < D) {
+            const int c = lane;
+            for (int i = 0; i < c; ++i) A[i * m + c] = c_make(0.0, 0.0);
+            A[c * m + c] = c_make(1.0 / V[c * m + c].x, 0.0);
+            for (int i = c + 1; i < D; ++i) {
+                cplx acc = c_make(0.0, 0.0);
+                for (int j = c; j < i; ++j) c_fma(acc, V[i * m + j], A[j * m + c]);
+                const double dinv = 1.0 / V[i * m + i].x;
+                A[i * m + c] = c_make(-acc.x * dinv, -acc.y * dinv);
+            }
+        }
+        __syncthreads();
+        // B^-1 = Linv^H Linv :  (d1,d2) = sum_{j >= d2} conj(Linv[j][d1]) Linv[j][d2]
+        for (int e = lane; e < NE; e += 64) {
+            int d1 = 0, rem = e;
+            while (rem >= D - d1) {
+                rem -= D - d1;
+                ++d1;
+            }
+            const int d2 = d1 + rem;
+            cplx v = c_make(0.0, 0.0);
+            for (int j = d2; j < D; ++j) c_cfma(v, A[j * m + d1], A[j * m + d2]);
+            if (d1 == d2) {
+                v.y = 0.0;
+            } else {
+                v.x *= 2.0;
+                v.y *= 2.0;
+            }
+            Mq[((int64_t)f * NE + e) * K + k] = v;
+        }
+    } else {
+        if (lane == 0 && slow_count) atomicAdd(slow_count, 1);
+        jacobi_eigh_wave(A, V, m, lane, 20);
+        double lmax = -INFINITY;
+        for (int i = lane; i < D; i += 64) lmax = fmax(lmax, A[i * m + i].x);
+        lmax = wave_max(lmax);
+        for (int i = lane; i < D; i += 64) {
+            double l = A[i * m + i].x / fmax(lmax, GSS_TINY);
+            l = fmax(l, eig_floor);
+            lam[i] = 1.0 / l;
+            ld += log(l);
+        }
+        ld = wave_sum(ld);
+        __syncthreads();
+        for (int e = lane; e < NE; e += 64) {
+            int d1 = 0, rem = e;
+            while (rem >= D - d1) {
+                rem -= D - d1;
+                ++d1;
+            }
+            const int d2 = d1 + rem;
             cplx v = c_make(0.0, 0.0);
             for (int j = 0; j < D; ++j) {
                 const cplx a = V[d1 * m + j], b = V[d2 * m + j];
@@ -313,8 +430,9 @@ __global__ __launch_bounds__(64) void em_eig_kernel(const cplx *__restrict__ Bp,
                 v.x *= 2.0;
                 v.y *= 2.0;
             }
-            Mq[((int64_t)f * NE + tri_index(d1, d2, D)) * K + k] = v;
+            Mq[((int64_t)f * NE + e) * K + k] = v;
         }
+    }
     if (lane == 0) {
         logdet[f * K + k] = ld;
         pi[f * K + k] = sg / (double)T;
@@ -421,13 +539,13 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     const size_t lds = em_step_lds(D, K);
     GSS_REQUIRE(ctx, lds <= 160 * 1024, GSS_ERR_UNSUPPORTED, "cacgmm: D=%d K=%d LDS", D, K);
     const int m = D + (D & 1);
-    const size_t eig_lds =
-        (sizeof(cplx) * 2 * m * m + sizeof(double) * m + sizeof(JacobiScratch) + 15) / 16 * 16;
+    const size_t eig_lds = (sizeof(cplx) * 2 * m * m + sizeof(double) * m + 15) / 16 * 16;
+    const int force_eigh = getenv("GSS_FORCE_EIGH") != nullptr;
 
     auto eig = [&]() -> int {
         GSS_PROF(ctx, "em_eig");
         hipLaunchKernelGGL(em_eig_kernel, dim3(K, F), dim3(64), eig_lds, ctx->stream, a.Bp, a.Sg,
-                           a.nch, D, K, T, 1e-10, Mq, logdet, pi);
+                           a.nch, D, K, T, 1e-10, force_eigh, Mq, logdet, pi, (int *)nullptr);
         GSS_LAUNCH_CHECK(ctx, "em_eig_kernel");
         return GSS_OK;
     };

@@ -73,6 +73,7 @@ extern "C" int gss_destroy(gss_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     free_tables(ctx);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->wpe_tiles) (void)hipFree(ctx->wpe_tiles);
     for (auto &p : ctx->prof_pending) {
         (void)hipEventDestroy(p.start);
         (void)hipEventDestroy(p.stop);

@@ -95,6 +95,10 @@ struct gss_ctx {
     double *win_synthesis = nullptr;  // device, stft_size
     cplx *twiddle = nullptr;          // device, stft_size/2: exp(-2 pi i j / size)
 
+    // WPE tile lists (device), rebuilt when (taps, delay, D) changes
+    void *wpe_tiles = nullptr;
+    int wpe_tiles_key[3] = {-1, -1, -1};
+
     // profiling
     bool profiling = false;
     std::vector<ProfEntry> prof_pending;

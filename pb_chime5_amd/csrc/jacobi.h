@@ -8,49 +8,54 @@
 // pb_chime5/math/solve.py:95-114).  Jacobi is used because it is branch-free
 // across lanes, needs no pivoting, and resolves small eigenvalues to high
 // relative accuracy -- the CACGMM floors eigenvalues at 1e-10 of the largest.
+//
+// Lane mapping: lane = (grp = lane >> 4, pr = lane & 15).  Every lane keeps the
+// rotation of pair `pr` in registers (the four groups compute it redundantly),
+// and group `grp` applies it to rows / columns grp, grp+4, ...  No integer
+// division, no rotation parameters in LDS, two barriers per rotation set.
 #pragma once
 #include "gss_internal.h"
-
-struct JacobiScratch {
-    double c[16];
-    cplx s[16];
-    int p[16], q[16];
-};
 
 // A: m x m (m even, <= 32), row-major, Hermitian on entry; on exit diag(A) holds
 // the eigenvalues.  V: m x m, on exit column j is the eigenvector of A[j][j].
 // If m was padded from an odd size the pad row/column must be zero on entry; it
-// then stays decoupled.
-__device__ inline int jacobi_eigh_wave(cplx *A, cplx *V, JacobiScratch *js, int m, int lane,
-                                       int max_sweeps) {
+// then stays decoupled.  Returns the number of sweeps.
+__device__ inline int jacobi_eigh_wave(cplx *A, cplx *V, int m, int lane, int max_sweeps) {
     const int half = m >> 1;
-    for (int idx = lane; idx < m * m; idx += 64) {
-        const int i = idx / m, j = idx - i * m;
-        V[idx] = c_make(i == j ? 1.0 : 0.0, 0.0);
-    }
+    const int pr = lane & 15, grp = lane >> 4;
+    const bool active = pr < half;
+    for (int i = grp; i < m; i += 4)
+        for (int j = pr; j < m; j += 16) V[i * m + j] = c_make(i == j ? 1.0 : 0.0, 0.0);
     __syncthreads();
     int sweep = 0;
+    bool last = false;
     for (; sweep < max_sweeps; ++sweep) {
-        // convergence: off-diagonal mass against the total
+        // off-diagonal mass against the total; once it is below 1e-20 of the total
+        // the (quadratically convergent) next sweep reaches the rounding floor
         double off = 0.0, dia = 0.0;
-        for (int idx = lane; idx < m * m; idx += 64) {
-            const int i = idx / m, j = idx - i * m;
-            const double v = c_abs2(A[idx]);
-            if (i == j) dia += v; else off += v;
-        }
+        for (int i = grp; i < m; i += 4)
+            for (int j = pr; j < m; j += 16) {
+                const double v = c_abs2(A[i * m + j]);
+                if (i == j) dia += v; else off += v;
+            }
         off = wave_sum(off);
         dia = wave_sum(dia);
-        if (off <= 1e-31 * (dia + off)) break;
+        if (last || off <= 1e-30 * (dia + off)) break;
+        if (off <= 1e-20 * (dia + off)) last = true;
 
         for (int step = 0; step < m - 1; ++step) {
-            if (lane < half) {
-                int p, q;
-                if (lane == 0) {
+            int p = 0, q = 1;
+            double c = 1.0;
+            cplx s = c_make(0.0, 0.0);
+            if (active) {
+                if (pr == 0) {
                     p = m - 1;
                     q = step;
                 } else {
-                    p = (step + lane) % (m - 1);
-                    q = (step - lane + (m - 1)) % (m - 1);
+                    p = step + pr;
+                    if (p >= m - 1) p -= m - 1;
+                    q = step - pr;
+                    if (q < 0) q += m - 1;
                 }
                 if (p > q) {
                     const int t = p;
@@ -60,8 +65,6 @@ __device__ inline int jacobi_eigh_wave(cplx *A, cplx *V, JacobiScratch *js, int 
                 const double a = A[p * m + p].x, d = A[q * m + q].x;
                 const cplx b = A[p * m + q];
                 const double babs = hypot(b.x, b.y);
-                double c = 1.0;
-                cplx s = c_make(0.0, 0.0);
                 if (babs > 0.0) {
                     const double tau = (d - a) / (2.0 * babs);
                     const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
@@ -69,56 +72,47 @@ __device__ inline int jacobi_eigh_wave(cplx *A, cplx *V, JacobiScratch *js, int 
                     const double sn = t * c;
                     s = c_make(sn * (b.x / babs), sn * (b.y / babs));
                 }
-                js->c[lane] = c;
-                js->s[lane] = s;
-                js->p[lane] = p;
-                js->q[lane] = q;
+            }
+            // column update  A <- A J,  V <- V J   (rows grp, grp + 4, ...)
+            if (active) {
+                for (int i = grp; i < m; i += 4) {
+                    {
+                        const cplx ap = A[i * m + p], aq = A[i * m + q];
+                        // A'_ip = A_ip c - A_iq conj(s) ;  A'_iq = A_ip s + A_iq c
+                        cplx np_ = c_scale(ap, c), nq_ = c_scale(aq, c);
+                        np_.x -= aq.x * s.x + aq.y * s.y;
+                        np_.y -= aq.y * s.x - aq.x * s.y;
+                        nq_.x += ap.x * s.x - ap.y * s.y;
+                        nq_.y += ap.x * s.y + ap.y * s.x;
+                        A[i * m + p] = np_;
+                        A[i * m + q] = nq_;
+                    }
+                    {
+                        const cplx vp = V[i * m + p], vq = V[i * m + q];
+                        cplx np_ = c_scale(vp, c), nq_ = c_scale(vq, c);
+                        np_.x -= vq.x * s.x + vq.y * s.y;
+                        np_.y -= vq.y * s.x - vq.x * s.y;
+                        nq_.x += vp.x * s.x - vp.y * s.y;
+                        nq_.y += vp.x * s.y + vp.y * s.x;
+                        V[i * m + p] = np_;
+                        V[i * m + q] = nq_;
+                    }
+                }
             }
             __syncthreads();
-            // column update  A <- A J,  V <- V J   (item = (row i, pair))
-            for (int it = lane; it < m * half; it += 64) {
-                const int i = it / half, pr = it - i * half;
-                const int p = js->p[pr], q = js->q[pr];
-                const double c = js->c[pr];
-                const cplx s = js->s[pr];
-                {
-                    const cplx ap = A[i * m + p], aq = A[i * m + q];
-                    // A'_ip = A_ip c - A_iq conj(s) ;  A'_iq = A_ip s + A_iq c
+            // row update  A <- J^H A   (columns grp, grp + 4, ...)
+            if (active) {
+                for (int j = grp; j < m; j += 4) {
+                    const cplx ap = A[p * m + j], aq = A[q * m + j];
+                    // A'_pj = c A_pj - s A_qj ;  A'_qj = conj(s) A_pj + c A_qj
                     cplx np_ = c_scale(ap, c), nq_ = c_scale(aq, c);
-                    np_.x -= aq.x * s.x + aq.y * s.y;
-                    np_.y -= aq.y * s.x - aq.x * s.y;
-                    nq_.x += ap.x * s.x - ap.y * s.y;
-                    nq_.y += ap.x * s.y + ap.y * s.x;
-                    A[i * m + p] = np_;
-                    A[i * m + q] = nq_;
+                    np_.x -= s.x * aq.x - s.y * aq.y;
+                    np_.y -= s.x * aq.y + s.y * aq.x;
+                    nq_.x += s.x * ap.x + s.y * ap.y;
+                    nq_.y += s.x * ap.y - s.y * ap.x;
+                    A[p * m + j] = np_;
+                    A[q * m + j] = nq_;
                 }
-                {
-                    const cplx vp = V[i * m + p], vq = V[i * m + q];
-                    cplx np_ = c_scale(vp, c), nq_ = c_scale(vq, c);
-                    np_.x -= vq.x * s.x + vq.y * s.y;
-                    np_.y -= vq.y * s.x - vq.x * s.y;
-                    nq_.x += vp.x * s.x - vp.y * s.y;
-                    nq_.y += vp.x * s.y + vp.y * s.x;
-                    V[i * m + p] = np_;
-                    V[i * m + q] = nq_;
-                }
-            }
-            __syncthreads();
-            // row update  A <- J^H A   (item = (pair, column j))
-            for (int it = lane; it < m * half; it += 64) {
-                const int pr = it / m, j = it - pr * m;
-                const int p = js->p[pr], q = js->q[pr];
-                const double c = js->c[pr];
-                const cplx s = js->s[pr];
-                const cplx ap = A[p * m + j], aq = A[q * m + j];
-                // A'_pj = c A_pj - s A_qj ;  A'_qj = conj(s) A_pj + c A_qj
-                cplx np_ = c_scale(ap, c), nq_ = c_scale(aq, c);
-                np_.x -= s.x * aq.x - s.y * aq.y;
-                np_.y -= s.x * aq.y + s.y * aq.x;
-                nq_.x += s.x * ap.x + s.y * ap.y;
-                nq_.y += s.x * ap.y - s.y * ap.x;
-                A[p * m + j] = np_;
-                A[q * m + j] = nq_;
             }
             __syncthreads();
         }

@@ -141,10 +141,9 @@ __global__ __launch_bounds__(64) void mvdr_solve_kernel(
     cplx *aug = reinterpret_cast<cplx *>(smem);   // D x 2D : [Phi_N | Phi_X] -> [U | Z] -> Psi
     cplx *JA = aug + D * W2;                       // m * m
     cplx *JV = JA + m * m;                         // m * m
-    JacobiScratch *js = reinterpret_cast<JacobiScratch *>(JV + m * m);
     // flags live in the dynamic region too: a static __shared__ in front of it
     // would break its 16-byte alignment
-    int *flags = reinterpret_cast<int *>(js + 1);
+    int *flags = reinterpret_cast<int *>(JV + m * m);
     int &s_piv = flags[0];
     int &s_singular = flags[1];
     const int f = blockIdx.x, lane = threadIdx.x;
@@ -265,7 +264,7 @@ __global__ __launch_bounds__(64) void mvdr_solve_kernel(
             JA[idx] = (i < D && jx < D) ? PhiN[i * D + jx] : c_make(0.0, 0.0);
         }
         __syncthreads();
-        jacobi_eigh_wave(JA, JV, js, m, lane, 16);
+        jacobi_eigh_wave(JA, JV, m, lane, 20);
         double lmax = 0.0;
         for (int i = lane; i < D; i += 64) lmax = fmax(lmax, fabs(JA[i * m + i].x));
         lmax = wave_max(lmax);
@@ -476,7 +475,7 @@ int mvdr_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double 
         GSS_PROF(ctx, "mvdr_solve");
         const int m = D + (D & 1);
         const size_t lds = (sizeof(cplx) * ((size_t)D * 2 * D + 2 * (size_t)m * m) +
-                            sizeof(JacobiScratch) + 16 + 15) / 16 * 16;
+                            16 + 15) / 16 * 16;
         if (lds > 64 * 1024)
             GSS_HIP_CHECK(ctx, hipFuncSetAttribute(
                                    reinterpret_cast<const void *>(mvdr_solve_kernel),

@@ -13,6 +13,8 @@
 // both slices of one sliding-window Gram matrix -- the only true dense
 // contraction of the hot path, done here with the f64 MFMA
 // (v_mfma_f64_16x16x4_f64) straight out of an LDS copy of the window.
+#include <algorithm>
+
 #include "gss_internal.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -150,84 +152,236 @@ __global__ __launch_bounds__(256) void wpe_corr_kernel(
 }
 
 // ------------------------------------------------------------------ solve
-// Augmented right-looking Cholesky  [R | P] -> [U | Z] with R = U^H U (upper
-// triangle of R is the input), then back substitution U G = Z.  G overwrites P.
+// G = solve(R, P) for every frequency: blocked right-looking Cholesky R = U^H U on
+// the upper triangle with the right-hand sides carried along ([R | P] -> [U | Z],
+// Z = U^-H P), then blocked back substitution U G = Z (G overwrites P).
+// Per block column of CH_NB = 48:
+//   chol_panel   grid (F):        factor the 48 x 48 diagonal block in LDS, then
+//                                 forward-substitute the row panel (one column of
+//                                 the trailing matrix or of P per thread)
+//   chol_update  grid (tiles, F): trailing update C -= U_J^H U_J with the f64 MFMA,
+//                                 one 48 x 48 tile per wave, accumulators loaded
+//                                 from / stored to global memory in fragment layout
 // A non-positive pivot (exactly singular system, e.g. an all-zero channel) zeroes
-// the row, which reproduces the minimum-norm lstsq fallback of stable_solve
-// (pb_chime5/math/solve.py:95-114) for zero rows/columns.
-__global__ __launch_bounds__(256) void wpe_solve_kernel(cplx *__restrict__ R,
-                                                        cplx *__restrict__ P, int n, int D) {
+// that row, which reproduces the minimum-norm lstsq fallback of stable_solve
+// (pb_chime5/math/solve.py:95-114) for zero rows / columns.
+constexpr int CH_NB = 48;
+
+__global__ __launch_bounds__(256) void chol_panel_kernel(cplx *__restrict__ R,
+                                                         cplx *__restrict__ P, int n, int D,
+                                                         int j0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cplx *rowj = reinterpret_cast<cplx *>(smem);   // n + D
-    double &s_dinv = *reinterpret_cast<double *>(rowj + n + D);
-    const int f = blockIdx.x;
+    cplx *Ud = reinterpret_cast<cplx *>(smem);                       // CH_NB * CH_NB
+    double *dinv = reinterpret_cast<double *>(Ud + CH_NB * CH_NB);   // CH_NB
+    const int f = blockIdx.x, tid = threadIdx.x;
     cplx *A = R + (int64_t)f * n * n;
     cplx *Z = P + (int64_t)f * n * D;
-    const int tid = threadIdx.x;
+    const int nb = min(CH_NB, n - j0);
 
-    for (int j = 0; j < n; ++j) {
+    for (int idx = tid; idx < CH_NB * CH_NB; idx += blockDim.x) {
+        const int i = idx / CH_NB, k = idx - i * CH_NB;
+        cplx v = c_make(0.0, 0.0);
+        if (i < nb && k < nb && k >= i) v = A[(int64_t)(j0 + i) * n + j0 + k];
+        Ud[idx] = v;
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {
         if (tid == 0) {
-            const double a = A[(int64_t)j * n + j].x;
-            double d = 0.0, dinv = 0.0;
+            const double a = Ud[j * CH_NB + j].x;
+            double d = 0.0, di = 0.0;
             if (a > 0.0 && isfinite(a)) {
                 d = sqrt(a);
-                dinv = 1.0 / d;
+                di = 1.0 / d;
             }
-            A[(int64_t)j * n + j] = c_make(d, 0.0);
-            s_dinv = dinv;
+            Ud[j * CH_NB + j] = c_make(d, 0.0);
+            dinv[j] = di;
         }
         __syncthreads();
-        const double dinv = s_dinv;
-        const int m = n - j - 1;
-        for (int idx = tid; idx < m + D; idx += blockDim.x) {
-            cplx *p = idx < m ? &A[(int64_t)j * n + j + 1 + idx] : &Z[j * D + (idx - m)];
-            const cplx v = c_scale(*p, dinv);
-            *p = v;
-            rowj[idx] = v;
-        }
+        const double di = dinv[j];
+        for (int k = j + 1 + tid; k < nb; k += blockDim.x)
+            Ud[j * CH_NB + k] = c_scale(Ud[j * CH_NB + k], di);
         __syncthreads();
-        // trailing update: A[i][k] -= conj(U[j][i]) U[j][k]  (k >= i),  Z[i] -= conj(U[j][i]) Z[j]
-        const int tx = tid & 31, ty = tid >> 5;
-        for (int ii = ty; ii < m; ii += 8) {
-            const cplx u = rowj[ii];
-            if (u.x == 0.0 && u.y == 0.0) continue;
-            const int i = j + 1 + ii;
-            cplx *Ai = A + (int64_t)i * n;
-            for (int kk = ii + tx; kk < m; kk += 32) {
-                cplx v = Ai[j + 1 + kk];
-                const cplx r = rowj[kk];
-                v.x -= u.x * r.x + u.y * r.y;
-                v.y -= u.x * r.y - u.y * r.x;
-                Ai[j + 1 + kk] = v;
-            }
-            for (int dd = tx; dd < D; dd += 32) {
-                cplx v = Z[i * D + dd];
-                const cplx r = rowj[m + dd];
-                v.x -= u.x * r.x + u.y * r.y;
-                v.y -= u.x * r.y - u.y * r.x;
-                Z[i * D + dd] = v;
-            }
+        const int r = nb - j - 1;
+        for (int it = tid; it < r * r; it += blockDim.x) {
+            const int ii = it / r, kk = it - ii * r;
+            if (kk < ii) continue;
+            const int i = j + 1 + ii, k = j + 1 + kk;
+            const cplx u = Ud[j * CH_NB + i], w = Ud[j * CH_NB + k];
+            cplx v = Ud[i * CH_NB + k];
+            v.x -= u.x * w.x + u.y * w.y;
+            v.y -= u.x * w.y - u.y * w.x;
+            Ud[i * CH_NB + k] = v;
         }
         __syncthreads();
     }
-    // back substitution (column oriented): g_j = z_j / U[j][j]; z_i -= U[i][j] g_j (i < j)
-    for (int j = n - 1; j >= 0; --j) {
-        const double d = A[(int64_t)j * n + j].x;
-        const double dinv = d > 0.0 ? 1.0 / d : 0.0;
-        if (tid < D) {
-            const cplx g = c_scale(Z[j * D + tid], dinv);
-            Z[j * D + tid] = g;
-            rowj[tid] = g;
+    for (int idx = tid; idx < nb * nb; idx += blockDim.x) {
+        const int i = idx / nb, k = idx - i * nb;
+        if (k >= i) A[(int64_t)(j0 + i) * n + j0 + k] = Ud[i * CH_NB + k];
+    }
+    // row panel: x = U_JJ^-H a for every trailing column and every right-hand side
+    const int ntrail = n - j0 - nb;
+    for (int c = tid; c < ntrail + D; c += blockDim.x) {
+        cplx *col;
+        int64_t stride;
+        if (c < ntrail) {
+            col = A + (int64_t)j0 * n + j0 + nb + c;
+            stride = n;
+        } else {
+            col = Z + (int64_t)j0 * D + (c - ntrail);
+            stride = D;
+        }
+        cplx x[CH_NB];
+#pragma unroll
+        for (int i = 0; i < CH_NB; ++i) {
+            if (i < nb) {
+                cplx v = col[i * stride];
+#pragma unroll
+                for (int k = 0; k < i; ++k) {
+                    const cplx u = Ud[k * CH_NB + i];   // conj(U[k][i]) * x[k]
+                    v.x -= u.x * x[k].x + u.y * x[k].y;
+                    v.y -= u.x * x[k].y - u.y * x[k].x;
+                }
+                v = c_scale(v, dinv[i]);
+                x[i] = v;
+                col[i * stride] = v;
+            }
+        }
+    }
+}
+
+struct UpdTile {
+    int row_off, col_off, is_p, pad;
+};
+
+// grid (tile groups, F), block 256 = 4 waves, one 48 x 48 tile each.
+__global__ __launch_bounds__(256) void chol_update_kernel(cplx *__restrict__ R,
+                                                          cplx *__restrict__ P, int n, int D,
+                                                          int j0, int nb,
+                                                          const UpdTile *__restrict__ tiles,
+                                                          int ntiles) {
+    const int f = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile_id = blockIdx.x * 4 + wave;
+    if (tile_id >= ntiles) return;
+    const UpdTile tl = tiles[tile_id];
+    const int li = lane & 15, lk = lane >> 4;
+    cplx *A = R + (int64_t)f * n * n;
+    cplx *Z = P + (int64_t)f * n * D;
+    const cplx *panel = A + (int64_t)j0 * n;      // rows j0 .. j0+nb of U
+    const cplx *zpanel = Z + (int64_t)j0 * D;
+    const int ncols = tl.is_p ? D : n;
+
+    v4d acc_re[3][3], acc_im[3][3];
+    // load C in fragment layout: col = li, row = lk + 4 * reg
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = tl.row_off + 16 * a + lk + 4 * reg;
+                const int c = tl.col_off + 16 * b + li;
+                cplx v = c_make(0.0, 0.0);
+                if (r < n && c < ncols) v = tl.is_p ? Z[(int64_t)r * D + c] : A[(int64_t)r * n + c];
+                acc_re[a][b][reg] = v.x;
+                acc_im[a][b][reg] = v.y;
+            }
+    const int ksteps = (nb + 3) / 4;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int kk = 4 * ks + lk;
+        const bool kv = kk < nb;
+        double nar[3], nai[3], ai[3], br[3], bi[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int ri = tl.row_off + 16 * m + li;
+            cplx a = c_make(0.0, 0.0);
+            if (kv && ri < n) a = panel[(int64_t)kk * n + ri];
+            nar[m] = -a.x;
+            nai[m] = -a.y;
+            ai[m] = a.y;
+            const int ci = tl.col_off + 16 * m + li;
+            cplx b = c_make(0.0, 0.0);
+            if (kv && ci < ncols)
+                b = tl.is_p ? zpanel[(int64_t)kk * D + ci] : panel[(int64_t)kk * n + ci];
+            br[m] = b.x;
+            bi[m] = b.y;
+        }
+        // C -= conj(a) b :  re -= ar br + ai bi ;  im -= ar bi - ai br
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nar[a], br[b], acc_re[a][b], 0, 0, 0);
+                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nar[a], bi[b], acc_im[a][b], 0, 0, 0);
+            }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai[a], bi[b], acc_re[a][b], 0, 0, 0);
+                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], br[b], acc_im[a][b], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = tl.row_off + 16 * a + lk + 4 * reg;
+                const int c = tl.col_off + 16 * b + li;
+                if (r < n && c < ncols) {
+                    const cplx v = c_make(acc_re[a][b][reg], acc_im[a][b][reg]);
+                    if (tl.is_p) Z[(int64_t)r * D + c] = v;
+                    else A[(int64_t)r * n + c] = v;
+                }
+            }
+}
+
+// Blocked back substitution U G = Z, G overwrites Z.  grid (F), block 256.
+__global__ __launch_bounds__(256) void chol_backsolve_kernel(const cplx *__restrict__ R,
+                                                             cplx *__restrict__ P, int n, int D) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx *Ud = reinterpret_cast<cplx *>(smem);        // CH_NB * CH_NB
+    cplx *S = Ud + CH_NB * CH_NB;                      // CH_NB * D
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const cplx *A = R + (int64_t)f * n * n;
+    cplx *Z = P + (int64_t)f * n * D;
+    const int nblk = (n + CH_NB - 1) / CH_NB;
+    for (int J = nblk - 1; J >= 0; --J) {
+        const int j0 = J * CH_NB, nb = min(CH_NB, n - j0);
+        __syncthreads();
+        for (int idx = tid; idx < nb * nb; idx += blockDim.x) {
+            const int i = idx / nb, k = idx - i * nb;
+            Ud[i * CH_NB + k] = k >= i ? A[(int64_t)(j0 + i) * n + j0 + k] : c_make(0.0, 0.0);
+        }
+        // S = Z_J - U_J,>J G_>J
+        for (int idx = tid; idx < nb * D; idx += blockDim.x) {
+            const int i = idx / D, d = idx - i * D;
+            cplx v = Z[(int64_t)(j0 + i) * D + d];
+            const cplx *urow = A + (int64_t)(j0 + i) * n;
+            for (int k = j0 + nb; k < n; ++k) {
+                const cplx u = urow[k], g = Z[(int64_t)k * D + d];
+                v.x -= u.x * g.x - u.y * g.y;
+                v.y -= u.x * g.y + u.y * g.x;
+            }
+            S[idx] = v;
         }
         __syncthreads();
-        for (int idx = tid; idx < j * D; idx += blockDim.x) {
-            const int i = idx / D, dd = idx - i * D;
-            const cplx u = A[(int64_t)i * n + j];
-            const cplx g = rowj[dd];
-            cplx v = Z[idx];
-            v.x -= u.x * g.x - u.y * g.y;
-            v.y -= u.x * g.y + u.y * g.x;
-            Z[idx] = v;
+        // triangular solve inside the block, one right-hand side per thread
+        if (tid < D) {
+            for (int i = nb - 1; i >= 0; --i) {
+                cplx v = S[i * D + tid];
+                for (int k = i + 1; k < nb; ++k) {
+                    const cplx u = Ud[i * CH_NB + k], g = S[k * D + tid];
+                    v.x -= u.x * g.x - u.y * g.y;
+                    v.y -= u.x * g.y + u.y * g.x;
+                }
+                const double d = Ud[i * CH_NB + i].x;
+                v = c_scale(v, d > 0.0 ? 1.0 / d : 0.0);
+                S[i * D + tid] = v;
+                Z[(int64_t)(j0 + i) * D + tid] = v;
+            }
         }
         __syncthreads();
     }
@@ -314,7 +468,6 @@ size_t wpe_workspace_bytes(int F, int64_t T, int D, int taps, int delay) {
     b += align_up(sizeof(double) * (size_t)F * T);       // w
     b += align_up(sizeof(cplx) * (size_t)F * n * n);     // R
     b += align_up(sizeof(cplx) * (size_t)F * n * D);     // P / G
-    b += align_up(sizeof(CorrTile) * 1024);
     return b + 4096;
 }
 
@@ -332,20 +485,49 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     double *w = arena_alloc_t<double>(ctx, (size_t)F * T);
     cplx *R = arena_alloc_t<cplx>(ctx, (size_t)F * n * n);
     cplx *P = arena_alloc_t<cplx>(ctx, (size_t)F * n * D);
-    CorrTile *tiles_dev = arena_alloc_t<CorrTile>(ctx, 1024);
-    GSS_REQUIRE(ctx, w && R && P && tiles_dev, GSS_ERR_NOMEM, "wpe workspace");
+    GSS_REQUIRE(ctx, w && R && P, GSS_ERR_NOMEM, "wpe workspace");
 
+    // tile lists: correlation tiles, then one trailing-update list per block column
     std::vector<CorrTile> tiles;
     const int ntiles = corr_tiles(n, D, c, tiles);
-    GSS_REQUIRE(ctx, ntiles <= 1024, GSS_ERR_UNSUPPORTED, "wpe: taps*D=%d too large", n);
-    GSS_HIP_CHECK(ctx, hipMemcpyAsync(tiles_dev, tiles.data(), sizeof(CorrTile) * ntiles,
-                                      hipMemcpyHostToDevice, ctx->stream));
-    // the tile list lives on the host stack: make sure the copy has been staged
-    GSS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<UpdTile> upd;
+    std::vector<int> upd_start, upd_count;
+    {
+        const int nblk = (n + CH_NB - 1) / CH_NB;
+        for (int J = 0; J < nblk; ++J) {
+            upd_start.push_back((int)upd.size());
+            for (int I = J + 1; I < nblk; ++I) {
+                for (int Kb = I; Kb < nblk; ++Kb) upd.push_back({I * CH_NB, Kb * CH_NB, 0, 0});
+                for (int cc = 0; cc < D; cc += CH_NB) upd.push_back({I * CH_NB, cc, 1, 0});
+            }
+            upd_count.push_back((int)upd.size() - upd_start.back());
+        }
+    }
+    GSS_REQUIRE(ctx, ntiles <= 1024 && upd.size() <= 4096, GSS_ERR_UNSUPPORTED,
+                "wpe: taps*D=%d too large", n);
+    static_assert(sizeof(CorrTile) == sizeof(UpdTile), "tile structs share one buffer");
+    if (ctx->wpe_tiles_key[0] != taps || ctx->wpe_tiles_key[1] != delay ||
+        ctx->wpe_tiles_key[2] != D) {
+        GSS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (!ctx->wpe_tiles)
+            GSS_HIP_CHECK(ctx, hipMalloc(&ctx->wpe_tiles, sizeof(CorrTile) * (1024 + 4096)));
+        GSS_HIP_CHECK(ctx, hipMemcpy(ctx->wpe_tiles, tiles.data(), sizeof(CorrTile) * ntiles,
+                                     hipMemcpyHostToDevice));
+        if (!upd.empty())
+            GSS_HIP_CHECK(ctx, hipMemcpy(reinterpret_cast<CorrTile *>(ctx->wpe_tiles) + 1024,
+                                         upd.data(), sizeof(UpdTile) * upd.size(),
+                                         hipMemcpyHostToDevice));
+        ctx->wpe_tiles_key[0] = taps;
+        ctx->wpe_tiles_key[1] = delay;
+        ctx->wpe_tiles_key[2] = D;
+    }
+    CorrTile *tiles_dev = reinterpret_cast<CorrTile *>(ctx->wpe_tiles);
+    UpdTile *upd_dev = reinterpret_cast<UpdTile *>(tiles_dev + 1024);
 
     const int padf = corr_padf(D);
     const size_t corr_lds = sizeof(cplx) * (size_t)(CORR_KT + c + padf) * D + sizeof(double) * CORR_KT;
-    const size_t solve_lds = sizeof(cplx) * (size_t)(n + D) + 16;
+    const size_t panel_lds = sizeof(cplx) * CH_NB * CH_NB + sizeof(double) * CH_NB;
+    const size_t back_lds = sizeof(cplx) * (CH_NB * CH_NB + (size_t)CH_NB * D);
     const int ntq = 256 / D;
     const int tc = ntq * APPLY_TB;
     const size_t apply_lds = sizeof(cplx) * ((size_t)n * D + (size_t)(tc + c) * D);
@@ -375,9 +557,23 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         }
         {
             GSS_PROF(ctx, "wpe_solve");
-            hipLaunchKernelGGL(wpe_solve_kernel, dim3(F), dim3(256), solve_lds, ctx->stream, R, P,
-                               n, D);
-            GSS_LAUNCH_CHECK(ctx, "wpe_solve_kernel");
+            const int nblk = (n + CH_NB - 1) / CH_NB;
+            for (int J = 0; J < nblk; ++J) {
+                const int j0 = J * CH_NB, nb = std::min(CH_NB, n - j0);
+                hipLaunchKernelGGL(chol_panel_kernel, dim3(F), dim3(256), panel_lds, ctx->stream,
+                                   R, P, n, D, j0);
+                GSS_LAUNCH_CHECK(ctx, "chol_panel_kernel");
+                const int nupd = upd_count[J];
+                if (nupd > 0) {
+                    hipLaunchKernelGGL(chol_update_kernel, dim3((nupd + 3) / 4, F), dim3(256), 0,
+                                       ctx->stream, R, P, n, D, j0, nb, upd_dev + upd_start[J],
+                                       nupd);
+                    GSS_LAUNCH_CHECK(ctx, "chol_update_kernel");
+                }
+            }
+            hipLaunchKernelGGL(chol_backsolve_kernel, dim3(F), dim3(256), back_lds, ctx->stream, R,
+                               P, n, D);
+            GSS_LAUNCH_CHECK(ctx, "chol_backsolve_kernel");
         }
         {
             GSS_PROF(ctx, "wpe_apply");
