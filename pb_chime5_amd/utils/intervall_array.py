@@ -4,7 +4,11 @@ slice semantics the hot path needs (``arr[start:stop] -> dense bool`` at
 reference's ``ArrayIntervall`` (pb_chime5/utils/intervall_array.py:103-455; its
 Cython helpers ``cy_intersection`` / ``cy_non_intersection`` /
 ``cy_str_to_intervalls`` in utils/intervall_array_util.pyx are plain integer
-interval arithmetic and are done inline here).  Integer-exact.
+interval arithmetic and are done inline here).  Integer-exact, including the
+reference's lazy normalisation and its strict-inequality interval removal
+(intervall_array_util.pyx:8-31): assigning a bool array over a range only carves
+out stored intervals that start or end strictly inside the range, or strictly
+contain it -- a stored interval that begins exactly at ``start`` is left as is.
 """
 import numpy as np
 
@@ -65,13 +69,16 @@ class ArrayIntervall:
 
     @property
     def normalized_intervals(self):
+        self._intervals = _normalize(self._intervals)
         return self._intervals
 
-    intervals = normalized_intervals
+    @property
+    def intervals(self):
+        return self._intervals
 
     @property
     def _intervals_as_str(self):
-        return ', '.join(f'{s}:{e}' for s, e in self._intervals)
+        return ', '.join(f'{s}:{e}' for s, e in self.normalized_intervals)
 
     def __repr__(self):
         return f'{self.__class__.__name__}("{self._intervals_as_str}", shape={self.shape})'
@@ -91,25 +98,29 @@ class ArrayIntervall:
     def __setitem__(self, item, value):
         start, stop = self._parse_item(item)
         if np.isscalar(value) and value == 1:
-            self._intervals = _normalize(self._intervals + ((start, stop),))
+            self._intervals = tuple(self._intervals) + ((start, stop),)
         elif isinstance(value, (tuple, list, np.ndarray)):
             assert len(value) == stop - start, (start, stop, len(value))
             inner = ArrayIntervall.from_array(np.asarray(value, dtype=bool))._intervals
             kept = []
-            for s, e in self._intervals:      # remove [start, stop) from what is there
-                if s < start:
-                    kept.append((s, min(e, start)))
-                if e > stop:
-                    kept.append((max(s, stop), e))
-            self._intervals = _normalize(
-                kept + [(s + start, e + start) for s, e in inner])
+            for s, e in self._intervals:      # strict-inequality removal, see module doc
+                if start < s < stop:
+                    s = stop
+                elif start < e < stop:
+                    e = start
+                elif s < start and stop < e:
+                    kept.append((s, start))
+                    s = stop
+                if s < e:
+                    kept.append((s, e))
+            self._intervals = tuple(kept) + tuple((s + start, e + start) for s, e in inner)
         else:
             raise NotImplementedError(value)
 
     def __getitem__(self, item):
         start, stop = self._parse_item(item)
         arr = np.zeros(stop - start, dtype=bool)
-        for s, e in self._intervals:
+        for s, e in self.normalized_intervals:
             s, e = max(s, start), min(e, stop)
             if s < e:
                 arr[s - start:e - start] = True
