@@ -1,31 +1,32 @@
 // Guided CACGMM:  GSS.__call__ (/root/reference/pb_chime5/core.py:154-214) ->
 // pb_bss CACGMMTrainer.fit / CACGMM.predict, all 513 frequencies at once.
 //
-// One EM iteration = two launches:
-//   em_step  grid (chunks, F): a single fused pass over the frames of the chunk
-//            E-step   q_kt = | y^H B_k^-1 y |,  log p = -D ln q - ln det,  softmax
-//                     with weights pi_k and the activity mask, clip to [eps, 1-eps]
-//            M-step   partial sums of  (gamma_kt / q_kt) y y^H  and of gamma_kt
-//            (the posteriors and quadratic forms never leave the chip)
-//   em_eig   grid (K, F): reduce the partial sums, B_k = D * sum / sum(gamma),
-//            Hermitian eigendecomposition (Jacobi, LDS), eigenvalues / max, floor
-//            1e-10, then  B_k^-1 = V diag(1/lambda) V^H,  ln det,  pi_k.
+// One EM iteration = three launches (the split keeps register use low enough for
+// 4+ waves per SIMD, which is what hides the LDS / scalar-load latencies):
+//   em_estep grid (chunks, F): q_kt = | y^H B_k^-1 y |,  log p = -D ln q - ln det,
+//            softmax with weights pi_k and the activity mask, clip to [eps, 1-eps];
+//            writes the M-step weights  w_kt = gamma_kt / q_kt  (F,K,T) and partial
+//            sums of gamma.  (First iteration: gamma from the activity, q = 1;
+//            final predict: writes gamma.)
+//   em_mstep grid (chunks, F): partial sums of  w_kt y y^H  over the chunk's frames
+//   em_eig   grid (K, F): reduce the partial sums, B_k = D * sum / sum(gamma), then
+//            B_k^-1 and ln det (Cholesky when no eigenvalue can be floored, Jacobi
+//            eigendecomposition with the 1e-10 floor otherwise) and pi_k.
 //
 // Hermitian structure: with P_de(t) = y_d conj(y_e) (class independent, d <= e)
 //    q_kt   = sum_{d<=e}  Re(Mq_k,de) Re(P_de) + Im(Mq_k,de) Im(P_de)
 //    B_k,de = sum_t w_kt P_de(t)
 // where Mq holds B_k^-1 with the off-diagonals doubled.  That is 4 real FMAs per
 // (entry, class, frame) instead of 12 for the dense form.
-#include "gss_internal.h"
 #include <cstdlib>
 
+#include "gss_internal.h"
 #include "jacobi.h"
 
 namespace {
 
 constexpr int EM_TILE = 64;          // frames per tile (one per lane of a wave)
 constexpr int EM_TS = EM_TILE + 1;   // padded LDS row stride (complex elements)
-constexpr int EM_SLOTS = 3;          // ceil(528 / 256): accumulator slots per thread
 
 enum { MODE_FIRST = 0, MODE_EM = 1, MODE_PREDICT = 2 };
 
@@ -33,9 +34,9 @@ struct EmArgs {
     const cplx *Y;          // (F,T,D)
     const uint8_t *act;     // (K,act_stride), first T columns used
     int64_t act_stride;
-    const cplx *Mq;         // (F,NE,K)
     const double *logdet;   // (F,K)
     const double *pi;       // (F,K)
+    double *W;              // (F,K,T) M-step weights gamma / q
     cplx *Bp;               // (F,NCH,K,NE)
     double *Sg;             // (F,NCH,K)
     double *gamma;          // (F,K,T)   MODE_PREDICT only
@@ -45,208 +46,324 @@ struct EmArgs {
     double aff_eps;         // clip, 0 = none
 };
 
+// Load frames [t0, t0+64) of one frequency into LDS as ys[d][tl], optionally unit
+// normalised per frame (pb_bss normalize_observation).  `scratch` holds 4 * 64
+// doubles.  Thread (tl, g) loads channels d = g, g+4, ...
+template <bool NORMALISE>
+__device__ __forceinline__ void load_tile(const cplx *Yf, int D, int64_t t0, int64_t c1, int tl,
+                                          int g, cplx *ys, double *scratch) {
+    const int64_t t = t0 + tl;
+    double nrm = 0.0;
+    cplx v[8];   // D <= 32 -> at most 8 channels per group
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int d = g + 4 * j;
+        v[j] = c_make(0.0, 0.0);
+        if (d < D && t < c1) v[j] = Yf[t * D + d];
+        nrm += c_abs2(v[j]);
+    }
+    if (NORMALISE) {
+        scratch[g * EM_TILE + tl] = nrm;
+        __syncthreads();
+        nrm = scratch[tl] + scratch[EM_TILE + tl] + scratch[2 * EM_TILE + tl] +
+              scratch[3 * EM_TILE + tl];
+        nrm = sqrt(nrm);
+        if (nrm == 0.0) nrm = GSS_TINY;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = g + 4 * j;
+            if (d < D) ys[d * EM_TS + tl] = c_make(v[j].x / nrm, v[j].y / nrm);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = g + 4 * j;
+            if (d < D) ys[d * EM_TS + tl] = v[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ E-step
+// Mq is a separate __restrict__ argument: its reads are wave-uniform and are issued
+// as scalar loads, so the model never occupies LDS bandwidth.
 template <int K, int MODE>
-__global__ __launch_bounds__(256) void em_step_kernel(EmArgs a) {
+__global__ __launch_bounds__(256) void em_estep_kernel(EmArgs a, const cplx *__restrict__ Mq) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D = a.D, NE = a.NE;
-    cplx *ys = reinterpret_cast<cplx *>(smem);                 // D * EM_TS
-    cplx *Ms = ys + D * EM_TS;                                 // NE * K
-    double *qpart = reinterpret_cast<double *>(Ms + NE * K);   // 4 * K * EM_TILE
-    double *wk = qpart + 4 * K * EM_TILE;                      // K * EM_TILE
-    double *ldet = wk + K * EM_TILE;                           // K
-    double *pis = ldet + K;                                    // K
-    unsigned char *ed = reinterpret_cast<unsigned char *>(pis + K);   // 2 * NE
+    cplx *ys = reinterpret_cast<cplx *>(smem);                       // D * EM_TS
+    double *qpart = reinterpret_cast<double *>(ys + D * EM_TS);      // 4 * K * EM_TILE
+    double *lpS = qpart + 4 * K * EM_TILE;                           // K * EM_TILE
+    double *qqS = lpS + K * EM_TILE;                                 // K * EM_TILE
+    double *ldet = qqS + K * EM_TILE;                                // K
+    double *pis = ldet + K;                                          // K
+    double *vvS = qpart;   // the partial sums are dead once lp / qq are written
 
     const int f = blockIdx.y, chunk = blockIdx.x;
     const int tid = threadIdx.x;
-    const int tl = tid & 63, g = tid >> 6;
+    const int tl = tid & 63;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, uniform
     const int64_t T = a.T;
     const int64_t c0 = (int64_t)chunk * a.chunk_frames;
     const int64_t c1 = c0 + a.chunk_frames < T ? c0 + a.chunk_frames : T;
     const cplx *Yf = a.Y + (int64_t)f * T * D;
+    const cplx *Mf = Mq + (int64_t)f * NE * K;
 
-    for (int d1 = tid; d1 < D; d1 += blockDim.x)
-        for (int d2 = d1; d2 < D; ++d2) {
-            const int e = tri_index(d1, d2, D);
-            ed[2 * e] = (unsigned char)d1;
-            ed[2 * e + 1] = (unsigned char)d2;
-        }
-    if (MODE != MODE_FIRST) {
-        const cplx *Mf = a.Mq + (int64_t)f * NE * K;
-        for (int i = tid; i < NE * K; i += blockDim.x) Ms[i] = Mf[i];
-        if (tid < K) {
-            ldet[tid] = a.logdet[f * K + tid];
-            pis[tid] = a.pi[f * K + tid];
-        }
+    if (MODE != MODE_FIRST && tid < K) {
+        ldet[tid] = a.logdet[f * K + tid];
+        pis[tid] = a.pi[f * K + tid];
     }
-
-    cplx acc[EM_SLOTS][K];
-    double sg[K];
-#pragma unroll
-    for (int s = 0; s < EM_SLOTS; ++s)
-#pragma unroll
-        for (int k = 0; k < K; ++k) acc[s][k] = c_make(0.0, 0.0);
-#pragma unroll
-    for (int k = 0; k < K; ++k) sg[k] = 0.0;
-
-    const int neq = (NE + 3) / 4;
+    double sg[2] = {0.0, 0.0};   // sum of gamma for classes g and g + 4
 
     for (int64_t t0 = c0; t0 < c1; t0 += EM_TILE) {
-        __syncthreads();
-        // ---- load + unit-normalise the tile: ys[d][tl] = y_t[d] / ||y_t||
-        // thread (tl, g) loads channels d = g, g+4, ... of frame t0 + tl
-        {
-            const int64_t t = t0 + tl;
-            double nrm = 0.0;
-            cplx v[8];   // D <= 32 -> at most 8 channels per group
+        const int64_t t = t0 + tl;
+        const bool valid = t < c1;
+        if (MODE == MODE_FIRST) {
+            // GSS initialisation (core.py:156-160): where(act == 0, 1e-10, act) / sum_k
+            double ssum = 0.0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = g + 4 * j;
-                v[j] = c_make(0.0, 0.0);
-                if (d < D && t < c1) v[j] = Yf[t * D + d];
-                nrm += c_abs2(v[j]);
-            }
-            qpart[g * EM_TILE + tl] = nrm;
-            __syncthreads();
-            nrm = qpart[tl] + qpart[EM_TILE + tl] + qpart[2 * EM_TILE + tl] +
-                  qpart[3 * EM_TILE + tl];
-            nrm = sqrt(nrm);
-            if (nrm == 0.0) nrm = GSS_TINY;
+            for (int k = 0; k < K; ++k)
+                ssum += (valid && a.act[(int64_t)k * a.act_stride + t]) ? 1.0 : 1e-10;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = g + 4 * j;
-                if (d < D) ys[d * EM_TS + tl] = c_make(v[j].x / nrm, v[j].y / nrm);
+            for (int s = 0; s < 2; ++s) {
+                const int k = g + 4 * s;
+                if (k < K && valid) {
+                    const double v = a.act[(int64_t)k * a.act_stride + t] ? 1.0 : 1e-10;
+                    const double gk = v / ssum;
+                    sg[s] += gk;
+                    a.W[((int64_t)f * K + k) * T + t] = gk;          // quadratic form = 1
+                }
             }
+            continue;
         }
         __syncthreads();
-
-        // ---- E-step quadratic forms: partial sums over a quarter of the entries
-        if (MODE != MODE_FIRST) {
-            double q[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) q[k] = 0.0;
-            const int e0 = g * neq, e1 = min(e0 + neq, NE);
-            for (int e = e0; e < e1; ++e) {
-                const cplx y1 = ys[ed[2 * e] * EM_TS + tl];
-                const cplx y2 = ys[ed[2 * e + 1] * EM_TS + tl];
-                const double pr = y1.x * y2.x + y1.y * y2.y;
-                const double pim = y1.y * y2.x - y1.x * y2.y;
-                const cplx *mrow = Ms + e * K;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const cplx m = mrow[k];
-                    q[k] = fma(m.x, pr, q[k]);
-                    q[k] = fma(m.y, pim, q[k]);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < K; ++k) qpart[(g * K + k) * EM_TILE + tl] = q[k];
-        }
+        load_tile<true>(Yf, D, t0, c1, tl, g, ys, qpart);
         __syncthreads();
 
-        // ---- posteriors (first wave: one frame per lane)
-        if (g == 0) {
-            const int64_t t = t0 + tl;
-            const bool valid = t < c1;
-            double gam[K], qq[K];
-            if (MODE == MODE_FIRST) {
-                // GSS initialisation (core.py:156-160): where(act == 0, 1e-10, act) / sum_k
-                double s = 0.0;
+        // ---- quadratic forms.  Wave g takes the row pairs (p, D-1-p), p = g, g+4, ...
+        // (every pair holds D+1 entries: balanced); y_row stays in registers, the
+        // model row is read with wave-uniform (scalar) loads.
+        double q[K];
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const double v = (valid && a.act[(int64_t)k * a.act_stride + t]) ? 1.0 : 1e-10;
-                    gam[k] = v;
-                    s += v;
+        for (int k = 0; k < K; ++k) q[k] = 0.0;
+        const int npairs = (D + 1) / 2;
+        for (int p = g; p < npairs; p += 4) {
+#pragma unroll 1
+            for (int side = 0; side < 2; ++side) {
+                const int r = side == 0 ? p : D - 1 - p;
+                if (side == 1 && r == p) break;          // middle row of an odd D
+                const cplx y1 = ys[r * EM_TS + tl];
+                const cplx *mrow = Mf + (int64_t)tri_index(r, r, D) * K;
+                {
+                    const double pr = y1.x * y1.x + y1.y * y1.y;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) q[k] = fma(mrow[k].x, pr, q[k]);
                 }
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    gam[k] = gam[k] / s;
-                    qq[k] = 1.0;
-                }
-            } else {
-                double lp[K], mx = -INFINITY;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    double q = qpart[k * EM_TILE + tl] + qpart[(K + k) * EM_TILE + tl] +
-                               qpart[(2 * K + k) * EM_TILE + tl] +
-                               qpart[(3 * K + k) * EM_TILE + tl];
-                    q = fmax(fabs(q), GSS_TINY);
-                    qq[k] = q;
-                    lp[k] = -(double)D * log(q) - ldet[k];
-                    mx = fmax(mx, lp[k]);
-                }
-                double s = 0.0;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    double v = exp(lp[k] - mx) * pis[k];
-                    if (a.masked) v *= (valid && a.act[(int64_t)k * a.act_stride + t]) ? 1.0 : 0.0;
-                    gam[k] = v;
-                    s += v;
-                }
-                s = fmax(s, GSS_TINY);
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    double v = gam[k] / s;
-                    if (a.aff_eps != 0.0) v = fmin(fmax(v, a.aff_eps), 1.0 - a.aff_eps);
-                    gam[k] = v;
-                }
-            }
-            if (MODE == MODE_PREDICT) {
-                if (valid) {
-#pragma unroll
-                    for (int k = 0; k < K; ++k)
-                        a.gamma[((int64_t)f * K + k) * T + t] = gam[k];
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const double gk = valid ? gam[k] : 0.0;
-                    sg[k] += gk;
-                    wk[k * EM_TILE + tl] = gk / fmax(qq[k], 10.0 * GSS_TINY);
-                }
-            }
-        }
-        if (MODE == MODE_PREDICT) continue;
-        __syncthreads();
-
-        // ---- M-step accumulation: thread owns entries tid, tid+256, tid+512
-        const int nfr = (int)min((int64_t)EM_TILE, c1 - t0);
-#pragma unroll
-        for (int s = 0; s < EM_SLOTS; ++s) {
-            const int e = tid + 256 * s;
-            if (e < NE) {
-                const cplx *r1 = ys + ed[2 * e] * EM_TS;
-                const cplx *r2 = ys + ed[2 * e + 1] * EM_TS;
-                for (int j = 0; j < nfr; ++j) {
-                    const cplx y1 = r1[j], y2 = r2[j];
+                for (int d2 = r + 1; d2 < D; ++d2) {
+                    mrow += K;
+                    const cplx y2 = ys[d2 * EM_TS + tl];
                     const double pr = y1.x * y2.x + y1.y * y2.y;
                     const double pim = y1.y * y2.x - y1.x * y2.y;
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const double w = wk[k * EM_TILE + j];
-                        acc[s][k].x = fma(w, pr, acc[s][k].x);
-                        acc[s][k].y = fma(w, pim, acc[s][k].y);
+                        const cplx m = mrow[k];
+                        q[k] = fma(m.x, pr, q[k]);
+                        q[k] = fma(m.y, pim, q[k]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) qpart[(g * K + k) * EM_TILE + tl] = q[k];
+        __syncthreads();
+        // ---- log-likelihoods: thread (tl, g) handles classes g and g + 4
+        double myq[2] = {1.0, 1.0};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = g + 4 * s;
+            if (k < K) {
+                double qv = qpart[k * EM_TILE + tl] + qpart[(K + k) * EM_TILE + tl] +
+                            qpart[(2 * K + k) * EM_TILE + tl] + qpart[(3 * K + k) * EM_TILE + tl];
+                qv = fmax(fabs(qv), GSS_TINY);
+                myq[s] = qv;
+                lpS[k * EM_TILE + tl] = -(double)D * log(qv) - ldet[k];
+            }
+        }
+        __syncthreads();
+        double mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < K; ++k) mx = fmax(mx, lpS[k * EM_TILE + tl]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = g + 4 * s;
+            if (k < K) {
+                double v = exp(lpS[k * EM_TILE + tl] - mx) * pis[k];
+                if (a.masked) v *= (valid && a.act[(int64_t)k * a.act_stride + t]) ? 1.0 : 0.0;
+                vvS[k * EM_TILE + tl] = v;
+            }
+        }
+        __syncthreads();
+        double ssum = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) ssum += vvS[k * EM_TILE + tl];
+        ssum = fmax(ssum, GSS_TINY);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = g + 4 * s;
+            if (k < K && valid) {
+                double gam = vvS[k * EM_TILE + tl] / ssum;
+                if (a.aff_eps != 0.0) gam = fmin(fmax(gam, a.aff_eps), 1.0 - a.aff_eps);
+                if (MODE == MODE_PREDICT) {
+                    a.gamma[((int64_t)f * K + k) * T + t] = gam;
+                } else {
+                    sg[s] += gam;
+                    a.W[((int64_t)f * K + k) * T + t] = gam / fmax(myq[s], 10.0 * GSS_TINY);
+                }
+            }
+        }
+    }
+    if (MODE == MODE_PREDICT) return;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int k = g + 4 * s;
+        const double tot = wave_sum(sg[s]);
+        if (k < K && tl == 0) a.Sg[((int64_t)f * a.nch + chunk) * K + k] = tot;
+    }
+}
+
+// ------------------------------------------------------------------ M-step
+// Partial sums over a chunk of frames of  w_k(t) y y^H  for KW weight rows, upper
+// triangle in 2 x 2 register blocks; thread = (block, frame group).  Shared by the
+// CACGMM M-step (unit-normalised y, K class weights) and by the PSD matrices of the
+// beamformer (raw y, target / distortion masks).
+struct WcovLds {
+    int Dp, nblk, nfg;
+    size_t ys, wk, scratch, blk, total;
+};
+
+__host__ __device__ inline WcovLds wcov_lds_layout(int D, int KW) {
+    WcovLds L;
+    L.Dp = D + (D & 1);
+    const int nb2 = L.Dp / 2;
+    L.nblk = nb2 * (nb2 + 1) / 2;
+    int nfg = 256 / L.nblk;
+    if (nfg > EM_TILE) nfg = EM_TILE;
+    if (nfg < 1) nfg = 1;
+    L.nfg = nfg;
+    size_t off = 0;
+    const size_t ys_bytes = sizeof(cplx) * (size_t)L.Dp * EM_TS;
+    const size_t red_bytes = sizeof(cplx) * (size_t)L.nblk * 4 * KW;
+    L.ys = off;                                   // the final reduction reuses the tile
+    off += ys_bytes > red_bytes ? ys_bytes : red_bytes;
+    L.wk = off;      off += sizeof(double) * KW * EM_TILE;
+    L.scratch = off; off += sizeof(double) * 4 * EM_TILE;
+    L.blk = off;     off += 2 * (size_t)L.nblk;
+    L.total = (off + 15) / 16 * 16;
+    return L;
+}
+
+template <int KW, bool NORMALISE>
+__global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
+                                                   const double *__restrict__ W, int64_t T, int D,
+                                                   int NE, int nch, int chunk_frames,
+                                                   cplx *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const WcovLds L = wcov_lds_layout(D, KW);
+    const int Dp = L.Dp;
+    cplx *ys = reinterpret_cast<cplx *>(smem + L.ys);
+    double *wk = reinterpret_cast<double *>(smem + L.wk);
+    double *scratch = reinterpret_cast<double *>(smem + L.scratch);
+    unsigned char *blk = reinterpret_cast<unsigned char *>(smem + L.blk);
+
+    const int f = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int tl = tid & 63, g = tid >> 6;
+    const int64_t c0 = (int64_t)chunk * chunk_frames;
+    const int64_t c1 = c0 + chunk_frames < T ? c0 + chunk_frames : T;
+    const cplx *Yf = Y + (int64_t)f * T * D;
+    const double *Wf = W + (int64_t)f * KW * T;
+
+    {
+        const int nb2 = Dp / 2;
+        for (int bi = tid; bi < nb2; bi += blockDim.x) {
+            int idx = bi * nb2 - (bi * (bi - 1)) / 2;
+            for (int bj = bi; bj < nb2; ++bj, ++idx) {
+                blk[2 * idx] = (unsigned char)bi;
+                blk[2 * idx + 1] = (unsigned char)bj;
+            }
+        }
+    }
+    if (Dp != D)
+        for (int j = tid; j < EM_TS; j += blockDim.x) ys[D * EM_TS + j] = c_make(0.0, 0.0);
+
+    const int mb = tid % L.nblk, fg = tid / L.nblk;
+    const bool m_active = fg < L.nfg;
+    cplx acc[4][KW];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int k = 0; k < KW; ++k) acc[s][k] = c_make(0.0, 0.0);
+
+    for (int64_t t0 = c0; t0 < c1; t0 += EM_TILE) {
+        __syncthreads();
+        load_tile<NORMALISE>(Yf, D, t0, c1, tl, g, ys, scratch);
+        for (int idx = tid; idx < KW * EM_TILE; idx += blockDim.x) {
+            const int k = idx / EM_TILE, j = idx - k * EM_TILE;
+            wk[idx] = t0 + j < c1 ? Wf[(int64_t)k * T + t0 + j] : 0.0;
+        }
+        __syncthreads();
+        if (m_active) {
+            const int nfr = (int)min((int64_t)EM_TILE, c1 - t0);
+            const int bi = blk[2 * mb], bj = blk[2 * mb + 1];
+            const cplx *ra0 = ys + (2 * bi) * EM_TS, *ra1 = ra0 + EM_TS;
+            const cplx *rb0 = ys + (2 * bj) * EM_TS, *rb1 = rb0 + EM_TS;
+            for (int j = fg; j < nfr; j += L.nfg) {
+                const cplx a0 = ra0[j], a1 = ra1[j], b0 = rb0[j], b1 = rb1[j];
+                double pr[4], pim[4];
+                pr[0] = a0.x * b0.x + a0.y * b0.y;  pim[0] = a0.y * b0.x - a0.x * b0.y;
+                pr[1] = a0.x * b1.x + a0.y * b1.y;  pim[1] = a0.y * b1.x - a0.x * b1.y;
+                pr[2] = a1.x * b0.x + a1.y * b0.y;  pim[2] = a1.y * b0.x - a1.x * b0.y;
+                pr[3] = a1.x * b1.x + a1.y * b1.y;  pim[3] = a1.y * b1.x - a1.x * b1.y;
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    const double w = wk[k * EM_TILE + j];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        acc[s][k].x = fma(w, pr[s], acc[s][k].x);
+                        acc[s][k].y = fma(w, pim[s], acc[s][k].y);
                     }
                 }
             }
         }
     }
-
-    if (MODE == MODE_PREDICT) return;
-    cplx *Bp = a.Bp + ((int64_t)f * a.nch + chunk) * K * NE;
+    // reduce the frame groups (group fg > 0 -> LDS -> group 0), then store
+    cplx *red = reinterpret_cast<cplx *>(smem + L.ys);
+    for (int r = 1; r < L.nfg; ++r) {
+        __syncthreads();
+        if (m_active && fg == r) {
 #pragma unroll
-    for (int s = 0; s < EM_SLOTS; ++s) {
-        const int e = tid + 256 * s;
-        if (e < NE) {
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int k = 0; k < K; ++k) Bp[k * NE + e] = acc[s][k];
+                for (int k = 0; k < KW; ++k) red[(mb * 4 + s) * KW + k] = acc[s][k];
+        }
+        __syncthreads();
+        if (fg == 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int k = 0; k < KW; ++k)
+                    acc[s][k] = c_add(acc[s][k], red[(mb * 4 + s) * KW + k]);
         }
     }
-    if (g == 0) {
+    if (fg == 0) {
+        cplx *pp = part + ((int64_t)f * nch + chunk) * KW * NE;
+        const int bi = blk[2 * mb], bj = blk[2 * mb + 1];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const double s = wave_sum(sg[k]);
-            if (tl == 0) a.Sg[((int64_t)f * a.nch + chunk) * K + k] = s;
+        for (int s = 0; s < 4; ++s) {
+            const int d1 = 2 * bi + (s >> 1), d2 = 2 * bj + (s & 1);
+            if (d1 <= d2 && d2 < D) {
+                const int e = tri_index(d1, d2, D);
+#pragma unroll
+                for (int k = 0; k < KW; ++k) pp[k * NE + e] = acc[s][k];
+            }
         }
     }
 }
@@ -439,11 +556,9 @@ __global__ __launch_bounds__(64) void em_eig_kernel(const cplx *__restrict__ Bp,
     }
 }
 
-size_t em_step_lds(int D, int K) {
-    const int NE = tri_count(D);
-    size_t b = sizeof(cplx) * ((size_t)D * EM_TS + (size_t)NE * K);
-    b += sizeof(double) * ((size_t)4 * K * EM_TILE + (size_t)K * EM_TILE + 2 * K);
-    b += 2 * NE;
+size_t em_estep_lds(int D, int K) {
+    size_t b = sizeof(cplx) * (size_t)D * EM_TS;
+    b += sizeof(double) * ((size_t)4 * K * EM_TILE + 2 * (size_t)K * EM_TILE + 2 * K);
     return (b + 15) / 16 * 16;
 }
 
@@ -458,48 +573,82 @@ int em_chunks(int F, int64_t T, int *chunk_frames) {
     return (int)((tiles + tiles_per_chunk - 1) / tiles_per_chunk);
 }
 
-template <int K>
-int launch_step(gss_ctx *ctx, int mode, const EmArgs &a, int F) {
-    const size_t lds = em_step_lds(a.D, K);
-    dim3 grid(a.nch, F), block(256);
-    if (lds > 64 * 1024) {
-        const void *fn = mode == MODE_FIRST
-                             ? reinterpret_cast<const void *>(em_step_kernel<K, MODE_FIRST>)
-                             : mode == MODE_EM
-                                   ? reinterpret_cast<const void *>(em_step_kernel<K, MODE_EM>)
-                                   : reinterpret_cast<const void *>(em_step_kernel<K, MODE_PREDICT>);
-        GSS_HIP_CHECK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+template <typename Kern>
+int raise_lds_limit(gss_ctx *ctx, Kern kern, size_t lds) {
+    if (lds > 64 * 1024)
+        GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)lds));
-    }
-    if (mode == MODE_FIRST) {
-        GSS_PROF(ctx, "em_step");
-        hipLaunchKernelGGL((em_step_kernel<K, MODE_FIRST>), grid, block, lds, ctx->stream, a);
-    } else if (mode == MODE_EM) {
-        GSS_PROF(ctx, "em_step");
-        hipLaunchKernelGGL((em_step_kernel<K, MODE_EM>), grid, block, lds, ctx->stream, a);
-    } else {
-        GSS_PROF(ctx, "em_predict");
-        hipLaunchKernelGGL((em_step_kernel<K, MODE_PREDICT>), grid, block, lds, ctx->stream, a);
-    }
-    GSS_LAUNCH_CHECK(ctx, "em_step_kernel");
     return GSS_OK;
 }
 
-int launch_step_k(gss_ctx *ctx, int K, int mode, const EmArgs &a, int F) {
-    switch (K) {
-        case 1: return launch_step<1>(ctx, mode, a, F);
-        case 2: return launch_step<2>(ctx, mode, a, F);
-        case 3: return launch_step<3>(ctx, mode, a, F);
-        case 4: return launch_step<4>(ctx, mode, a, F);
-        case 5: return launch_step<5>(ctx, mode, a, F);
-        case 6: return launch_step<6>(ctx, mode, a, F);
-        case 7: return launch_step<7>(ctx, mode, a, F);
-        case 8: return launch_step<8>(ctx, mode, a, F);
+template <int K>
+int launch_estep(gss_ctx *ctx, int mode, const EmArgs &a, const cplx *Mq, int F) {
+    const size_t lds = em_estep_lds(a.D, K);
+    dim3 grid(a.nch, F), block(256);
+    if (mode == MODE_FIRST) {
+        GSS_PROF(ctx, "em_estep");
+        hipLaunchKernelGGL((em_estep_kernel<K, MODE_FIRST>), grid, block, 0, ctx->stream, a, Mq);
+    } else if (mode == MODE_EM) {
+        GSS_TRY(raise_lds_limit(ctx, em_estep_kernel<K, MODE_EM>, lds));
+        GSS_PROF(ctx, "em_estep");
+        hipLaunchKernelGGL((em_estep_kernel<K, MODE_EM>), grid, block, lds, ctx->stream, a, Mq);
+    } else {
+        GSS_TRY(raise_lds_limit(ctx, em_estep_kernel<K, MODE_PREDICT>, lds));
+        GSS_PROF(ctx, "em_predict");
+        hipLaunchKernelGGL((em_estep_kernel<K, MODE_PREDICT>), grid, block, lds, ctx->stream, a,
+                           Mq);
     }
+    GSS_LAUNCH_CHECK(ctx, "em_estep_kernel");
+    return GSS_OK;
+}
+
+template <int K>
+int launch_mstep(gss_ctx *ctx, const EmArgs &a, int F) {
+    const size_t lds = wcov_lds_layout(a.D, K).total;
+    GSS_TRY(raise_lds_limit(ctx, wcov_kernel<K, true>, lds));
+    GSS_PROF(ctx, "em_mstep");
+    hipLaunchKernelGGL((wcov_kernel<K, true>), dim3(a.nch, F), dim3(256), lds, ctx->stream, a.Y,
+                       a.W, a.T, a.D, a.NE, a.nch, a.chunk_frames, a.Bp);
+    GSS_LAUNCH_CHECK(ctx, "wcov_kernel");
+    return GSS_OK;
+}
+
+#define GSS_K_SWITCH(K, CALL)                                              \
+    switch (K) {                                                           \
+        case 1: { constexpr int KK = 1; return CALL; }                     \
+        case 2: { constexpr int KK = 2; return CALL; }                     \
+        case 3: { constexpr int KK = 3; return CALL; }                     \
+        case 4: { constexpr int KK = 4; return CALL; }                     \
+        case 5: { constexpr int KK = 5; return CALL; }                     \
+        case 6: { constexpr int KK = 6; return CALL; }                     \
+        case 7: { constexpr int KK = 7; return CALL; }                     \
+        case 8: { constexpr int KK = 8; return CALL; }                     \
+    }
+
+int launch_estep_k(gss_ctx *ctx, int K, int mode, const EmArgs &a, const cplx *Mq, int F) {
+    GSS_K_SWITCH(K, launch_estep<KK>(ctx, mode, a, Mq, F));
+    return gss_fail(ctx, GSS_ERR_UNSUPPORTED, "cacgmm: K=%d", K);
+}
+
+int launch_mstep_k(gss_ctx *ctx, int K, const EmArgs &a, int F) {
+    GSS_K_SWITCH(K, launch_mstep<KK>(ctx, a, F));
     return gss_fail(ctx, GSS_ERR_UNSUPPORTED, "cacgmm: K=%d", K);
 }
 
 }  // namespace
+
+// PSD accumulation of the beamformer: same kernel, raw observations, two masks.
+// W = (F, 2, T) [target, distortion]; part = (F, nch, 2, NE).
+int psd_partials_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double *W2,
+                     int nch, int chunk_frames, cplx *part) {
+    const size_t lds = wcov_lds_layout(D, 2).total;
+    GSS_TRY(raise_lds_limit(ctx, wcov_kernel<2, false>, lds));
+    hipLaunchKernelGGL((wcov_kernel<2, false>), dim3(nch, F), dim3(256), lds, ctx->stream, Y, W2,
+                       T, D, tri_count(D), nch, chunk_frames, part);
+    GSS_LAUNCH_CHECK(ctx, "wcov_kernel");
+    return GSS_OK;
+}
 
 size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K) {
     const size_t NE = tri_count(D);
@@ -508,14 +657,14 @@ size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K) {
     size_t b = 0;
     b += align_up(sizeof(cplx) * (size_t)F * NE * K);            // Mq
     b += 2 * align_up(sizeof(double) * (size_t)F * K);           // logdet, pi
+    b += align_up(sizeof(double) * (size_t)F * K * T);           // W
     b += align_up(sizeof(cplx) * (size_t)F * nch * K * NE);      // Bp
     b += align_up(sizeof(double) * (size_t)F * nch * K);         // Sg
     return b + 4096;
 }
 
 int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8_t *act,
-               int64_t act_stride, int K,
-               int iterations, int iterations_post, double *gamma) {
+               int64_t act_stride, int K, int iterations, int iterations_post, double *gamma) {
     const int NE = tri_count(D);
     EmArgs a{};
     a.Y = Y;
@@ -528,16 +677,17 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     cplx *Mq = arena_alloc_t<cplx>(ctx, (size_t)F * NE * K);
     double *logdet = arena_alloc_t<double>(ctx, (size_t)F * K);
     double *pi = arena_alloc_t<double>(ctx, (size_t)F * K);
+    a.W = arena_alloc_t<double>(ctx, (size_t)F * K * T);
     a.Bp = arena_alloc_t<cplx>(ctx, (size_t)F * a.nch * K * NE);
     a.Sg = arena_alloc_t<double>(ctx, (size_t)F * a.nch * K);
-    GSS_REQUIRE(ctx, Mq && logdet && pi && a.Bp && a.Sg, GSS_ERR_NOMEM, "cacgmm workspace");
-    a.Mq = Mq;
+    GSS_REQUIRE(ctx, Mq && logdet && pi && a.W && a.Bp && a.Sg, GSS_ERR_NOMEM,
+                "cacgmm workspace");
     a.logdet = logdet;
     a.pi = pi;
     a.gamma = gamma;
 
-    const size_t lds = em_step_lds(D, K);
-    GSS_REQUIRE(ctx, lds <= 160 * 1024, GSS_ERR_UNSUPPORTED, "cacgmm: D=%d K=%d LDS", D, K);
+    GSS_REQUIRE(ctx, em_estep_lds(D, K) <= 160 * 1024 && wcov_lds_layout(D, K).total <= 160 * 1024,
+                GSS_ERR_UNSUPPORTED, "cacgmm: D=%d K=%d LDS", D, K);
     const int m = D + (D & 1);
     const size_t eig_lds = (sizeof(cplx) * 2 * m * m + sizeof(double) * m + 15) / 16 * 16;
     const int force_eigh = getenv("GSS_FORCE_EIGH") != nullptr;
@@ -554,7 +704,8 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     for (int it = 0; it < iterations; ++it) {
         a.masked = 1;
         a.aff_eps = 1e-10;
-        GSS_TRY(launch_step_k(ctx, K, it == 0 ? MODE_FIRST : MODE_EM, a, F));
+        GSS_TRY(launch_estep_k(ctx, K, it == 0 ? MODE_FIRST : MODE_EM, a, Mq, F));
+        GSS_TRY(launch_mstep_k(ctx, K, a, F));
         GSS_TRY(eig());
     }
     if (iterations_post > 1) {
@@ -562,13 +713,14 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
         for (int it = 0; it < iterations_post - 1; ++it) {
             a.masked = 0;
             a.aff_eps = 1e-10;
-            GSS_TRY(launch_step_k(ctx, K, MODE_EM, a, F));
+            GSS_TRY(launch_estep_k(ctx, K, MODE_EM, a, Mq, F));
+            GSS_TRY(launch_mstep_k(ctx, K, a, F));
             GSS_TRY(eig());
         }
     }
     // predict: affiliation_eps = 0; mask only when iterations_post == 0
     a.masked = iterations_post == 0 ? 1 : 0;
     a.aff_eps = 0.0;
-    GSS_TRY(launch_step_k(ctx, K, MODE_PREDICT, a, F));
+    GSS_TRY(launch_estep_k(ctx, K, MODE_PREDICT, a, Mq, F));
     return GSS_OK;
 }

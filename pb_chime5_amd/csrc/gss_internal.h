@@ -167,6 +167,9 @@ size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K);
 int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8_t *act,
                int64_t act_stride, int K, int iterations, int iterations_post, double *gamma);
 
+int psd_partials_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double *W2,
+                     int nch, int chunk_frames, cplx *part);
+
 size_t mvdr_workspace_bytes(int F, int64_t T, int D);
 int mvdr_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double *mx,
              const double *mn, int ban, cplx *Xhat, int32_t *ref_channel);

@@ -11,8 +11,6 @@
 namespace {
 
 constexpr int PSD_TILE = 64;
-constexpr int PSD_TS = PSD_TILE + 1;
-constexpr int PSD_SLOTS = 3;
 
 // gamma (F,K,T) -> target (F,T), distortion (F,T); Python slice semantics for the
 // zeroed context frames (masks[:, :start] = 0; if end > 0: masks[:, -end:] = 0).
@@ -34,85 +32,32 @@ __global__ void masks_kernel(const double *__restrict__ gamma, int F, int K, int
     mn[idx] = n;
 }
 
-// Partial sums of  m_X(t) y y^H,  m_N(t) y y^H,  m_X(t),  m_N(t)  over a chunk of
-// frames; upper triangle only.  grid (chunks, F), block 256.
-__global__ __launch_bounds__(256) void psd_kernel(const cplx *__restrict__ Y,
-                                                  const double *__restrict__ mx,
-                                                  const double *__restrict__ mn, int64_t T, int D,
-                                                  int NE, int nch, int chunk_frames,
-                                                  cplx *__restrict__ part,
-                                                  double *__restrict__ msum) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    cplx *ys = reinterpret_cast<cplx *>(smem);                      // D * PSD_TS
-    double *wk = reinterpret_cast<double *>(ys + D * PSD_TS);       // 2 * PSD_TILE
-    unsigned char *ed = reinterpret_cast<unsigned char *>(wk + 2 * PSD_TILE);
-    const int f = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-    const int tl = tid & 63, g = tid >> 6;
-    const int64_t c0 = (int64_t)chunk * chunk_frames;
-    const int64_t c1 = c0 + chunk_frames < T ? c0 + chunk_frames : T;
-    const cplx *Yf = Y + (int64_t)f * T * D;
-
-    for (int d1 = tid; d1 < D; d1 += blockDim.x)
-        for (int d2 = d1; d2 < D; ++d2) {
-            const int e = tri_index(d1, d2, D);
-            ed[2 * e] = (unsigned char)d1;
-            ed[2 * e + 1] = (unsigned char)d2;
-        }
-    cplx acc[PSD_SLOTS][2];
-#pragma unroll
-    for (int s = 0; s < PSD_SLOTS; ++s) acc[s][0] = acc[s][1] = c_make(0.0, 0.0);
+// Pack the two masks into the (F, 2, T) weight layout of the shared covariance
+// kernel (cacgmm.hip: wcov_kernel) and sum them over time.  grid (F), block 256.
+__global__ __launch_bounds__(256) void mask_pack_kernel(const double *__restrict__ mx,
+                                                        const double *__restrict__ mn, int64_t T,
+                                                        double *__restrict__ W2,
+                                                        double *__restrict__ msum) {
+    __shared__ double red[8];
+    const int f = blockIdx.x, tid = threadIdx.x;
     double sx = 0.0, sn = 0.0;
-
-    for (int64_t t0 = c0; t0 < c1; t0 += PSD_TILE) {
-        __syncthreads();
-        const int64_t t = t0 + tl;
-        for (int d = g; d < D; d += 4)
-            ys[d * PSD_TS + tl] = t < c1 ? Yf[t * D + d] : c_make(0.0, 0.0);
-        if (g == 0) {
-            const double a = t < c1 ? mx[(int64_t)f * T + t] : 0.0;
-            const double b = t < c1 ? mn[(int64_t)f * T + t] : 0.0;
-            wk[tl] = a;
-            wk[PSD_TILE + tl] = b;
-            sx += a;
-            sn += b;
-        }
-        __syncthreads();
-        const int nfr = (int)min((int64_t)PSD_TILE, c1 - t0);
-#pragma unroll
-        for (int s = 0; s < PSD_SLOTS; ++s) {
-            const int e = tid + 256 * s;
-            if (e < NE) {
-                const cplx *r1 = ys + ed[2 * e] * PSD_TS;
-                const cplx *r2 = ys + ed[2 * e + 1] * PSD_TS;
-                for (int j = 0; j < nfr; ++j) {
-                    const cplx y1 = r1[j], y2 = r2[j];
-                    const double pr = y1.x * y2.x + y1.y * y2.y;
-                    const double pim = y1.y * y2.x - y1.x * y2.y;
-                    const double a = wk[j], b = wk[PSD_TILE + j];
-                    acc[s][0].x = fma(a, pr, acc[s][0].x);
-                    acc[s][0].y = fma(a, pim, acc[s][0].y);
-                    acc[s][1].x = fma(b, pr, acc[s][1].x);
-                    acc[s][1].y = fma(b, pim, acc[s][1].y);
-                }
-            }
-        }
+    for (int64_t t = tid; t < T; t += blockDim.x) {
+        const double a = mx[(int64_t)f * T + t], b = mn[(int64_t)f * T + t];
+        W2[((int64_t)f * 2) * T + t] = a;
+        W2[((int64_t)f * 2 + 1) * T + t] = b;
+        sx += a;
+        sn += b;
     }
-    cplx *pp = part + ((int64_t)f * nch + chunk) * 2 * NE;
-#pragma unroll
-    for (int s = 0; s < PSD_SLOTS; ++s) {
-        const int e = tid + 256 * s;
-        if (e < NE) {
-            pp[e] = acc[s][0];
-            pp[NE + e] = acc[s][1];
-        }
+    sx = wave_sum(sx);
+    sn = wave_sum(sn);
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = sx;
+        red[4 + (tid >> 6)] = sn;
     }
-    if (g == 0) {
-        sx = wave_sum(sx);
-        sn = wave_sum(sn);
-        if (tl == 0) {
-            msum[((int64_t)f * nch + chunk) * 2] = sx;
-            msum[((int64_t)f * nch + chunk) * 2 + 1] = sn;
-        }
+    __syncthreads();
+    if (tid == 0) {
+        msum[f * 2] = (red[0] + red[1]) + (red[2] + red[3]);
+        msum[f * 2 + 1] = (red[4] + red[5]) + (red[6] + red[7]);
     }
 }
 
@@ -148,11 +93,7 @@ __global__ __launch_bounds__(64) void mvdr_solve_kernel(
     int &s_singular = flags[1];
     const int f = blockIdx.x, lane = threadIdx.x;
 
-    double sx = 0.0, sn = 0.0;
-    for (int c = 0; c < nch; ++c) {
-        sx += msum[((int64_t)f * nch + c) * 2];
-        sn += msum[((int64_t)f * nch + c) * 2 + 1];
-    }
+    const double sx = msum[f * 2], sn = msum[f * 2 + 1];
     const double dx = fmax(sx, 1e-10), dn = fmax(sn, 1e-10);
     cplx *PhiX = Phi + (int64_t)f * 2 * D * D;
     cplx *PhiN = PhiX + D * D;
@@ -443,7 +384,8 @@ size_t mvdr_workspace_bytes(int F, int64_t T, int D) {
     const int nch = psd_chunks(F, T, &cf);
     size_t b = 0;
     b += align_up(sizeof(cplx) * (size_t)F * nch * 2 * NE);
-    b += align_up(sizeof(double) * (size_t)F * nch * 2);
+    b += align_up(sizeof(double) * (size_t)F * 2);
+    b += align_up(sizeof(double) * (size_t)F * 2 * T);
     b += align_up(sizeof(cplx) * (size_t)F * 2 * D * D);
     b += align_up(sizeof(cplx) * (size_t)F * D * D);
     b += align_up(sizeof(cplx) * (size_t)F * D * 2);
@@ -457,19 +399,20 @@ int mvdr_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double 
     int cf;
     const int nch = psd_chunks(F, T, &cf);
     cplx *part = arena_alloc_t<cplx>(ctx, (size_t)F * nch * 2 * NE);
-    double *msum = arena_alloc_t<double>(ctx, (size_t)F * nch * 2);
+    double *msum = arena_alloc_t<double>(ctx, (size_t)F * 2);
+    double *W2 = arena_alloc_t<double>(ctx, (size_t)F * 2 * T);
     cplx *Phi = arena_alloc_t<cplx>(ctx, (size_t)F * 2 * D * D);
     cplx *W = arena_alloc_t<cplx>(ctx, (size_t)F * D * D);
     cplx *snr = arena_alloc_t<cplx>(ctx, (size_t)F * D * 2);
     int32_t *ref = arena_alloc_t<int32_t>(ctx, 4);
-    GSS_REQUIRE(ctx, part && msum && Phi && W && snr && ref, GSS_ERR_NOMEM, "mvdr workspace");
+    GSS_REQUIRE(ctx, part && msum && W2 && Phi && W && snr && ref, GSS_ERR_NOMEM,
+                "mvdr workspace");
     {
         GSS_PROF(ctx, "psd");
-        const size_t lds = (sizeof(cplx) * (size_t)D * PSD_TS + sizeof(double) * 2 * PSD_TILE +
-                            2 * NE + 15) / 16 * 16;
-        hipLaunchKernelGGL(psd_kernel, dim3(nch, F), dim3(256), lds, ctx->stream, Y, mx, mn, T, D,
-                           NE, nch, cf, part, msum);
-        GSS_LAUNCH_CHECK(ctx, "psd_kernel");
+        hipLaunchKernelGGL(mask_pack_kernel, dim3(F), dim3(256), 0, ctx->stream, mx, mn, T, W2,
+                           msum);
+        GSS_LAUNCH_CHECK(ctx, "mask_pack_kernel");
+        GSS_TRY(psd_partials_run(ctx, Y, F, T, D, W2, nch, cf, part));
     }
     {
         GSS_PROF(ctx, "mvdr_solve");

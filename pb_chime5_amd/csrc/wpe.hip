@@ -155,74 +155,123 @@ __global__ __launch_bounds__(256) void wpe_corr_kernel(
 // G = solve(R, P) for every frequency: blocked right-looking Cholesky R = U^H U on
 // the upper triangle with the right-hand sides carried along ([R | P] -> [U | Z],
 // Z = U^-H P), then blocked back substitution U G = Z (G overwrites P).
-// Per block column of CH_NB = 48:
-//   chol_panel   grid (F):        factor the 48 x 48 diagonal block in LDS, then
-//                                 forward-substitute the row panel (one column of
-//                                 the trailing matrix or of P per thread)
-//   chol_update  grid (tiles, F): trailing update C -= U_J^H U_J with the f64 MFMA,
-//                                 one 48 x 48 tile per wave, accumulators loaded
-//                                 from / stored to global memory in fragment layout
+// Per block column J of CH_NB = 48 rows:
+//   chol_diag    grid (F), one wave:   factor the 48 x 48 diagonal block in LDS and
+//                                      invert it: W = U_JJ^-H (lower triangular) is
+//                                      kept in the unused strictly-lower triangle
+//   chol_trsm    grid (chunks, F):     row panel  U_J = W A_J  (and Z_J = W P_J)
+//   chol_update  grid (tiles, F):      trailing update C -= U_J^H U_J with the f64
+//                                      MFMA, one 48 x 48 tile per wave, accumulators
+//                                      loaded from / stored to global memory in
+//                                      fragment layout, operands double-buffered
+//   chol_backsolve grid (F):           G_J = W^H (Z_J - U_J,>J G_>J), J descending
 // A non-positive pivot (exactly singular system, e.g. an all-zero channel) zeroes
 // that row, which reproduces the minimum-norm lstsq fallback of stable_solve
 // (pb_chime5/math/solve.py:95-114) for zero rows / columns.
 constexpr int CH_NB = 48;
+constexpr int TRSM_COLS = 32;
 
-__global__ __launch_bounds__(256) void chol_panel_kernel(cplx *__restrict__ R,
-                                                         cplx *__restrict__ P, int n, int D,
-                                                         int j0) {
+__global__ __launch_bounds__(256) void chol_diag_kernel(cplx *__restrict__ R, int n, int j0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx *Ud = reinterpret_cast<cplx *>(smem);                       // CH_NB * CH_NB
     double *dinv = reinterpret_cast<double *>(Ud + CH_NB * CH_NB);   // CH_NB
     const int f = blockIdx.x, tid = threadIdx.x;
+    // thread (ty, tx): 16 x 16 grid over the block, 3 x 3 elements each at most
+    const int tx = tid & 15, ty = tid >> 4;
+    cplx *A = R + (int64_t)f * n * n;
+    const int nb = min(CH_NB, n - j0);
+
+    for (int i = ty; i < nb; i += 16)
+        for (int k = tx; k < nb; k += 16)
+            Ud[i * CH_NB + k] = k >= i ? A[(int64_t)(j0 + i) * n + j0 + k] : c_make(0.0, 0.0);
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {
+        const double a = Ud[j * CH_NB + j].x;
+        double d = 0.0, di = 0.0;
+        if (a > 0.0 && isfinite(a)) {
+            d = sqrt(a);
+            di = 1.0 / d;
+        }
+        // every thread scales the row entries it needs itself (no extra barrier):
+        // u_i = U[j][i] = A[j][i] * di for i > j
+        for (int i = j + 1 + ty; i < nb; i += 16) {
+            const cplx u = c_scale(Ud[j * CH_NB + i], di);
+            for (int k = i + ((tx - i) & 15); k < nb; k += 16) {      // k >= i, k = tx mod 16
+                const cplx w = c_scale(Ud[j * CH_NB + k], di);
+                cplx v = Ud[i * CH_NB + k];
+                v.x -= u.x * w.x + u.y * w.y;
+                v.y -= u.x * w.y - u.y * w.x;
+                Ud[i * CH_NB + k] = v;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            Ud[j * CH_NB + j] = c_make(d, 0.0);
+            dinv[j] = di;
+        }
+        for (int k = j + 1 + tid; k < nb; k += blockDim.x)
+            Ud[j * CH_NB + k] = c_scale(Ud[j * CH_NB + k], di);
+        __syncthreads();
+    }
+    // W = U^-H (lower triangular, W[i][i] = dinv[i]), right-looking forward
+    // substitution on all columns at once; the strictly lower triangle of Ud holds
+    // first the running right-hand sides (initially 0 off the diagonal), then W.
+    for (int i = 0; i < nb; ++i) {
+        // x_i[c] = v[i][c] * dinv[i] for c <= i  (v[i][i] = 1)
+        const double di = dinv[i];
+        for (int c = tid; c < i; c += blockDim.x)
+            Ud[i * CH_NB + c] = c_scale(Ud[i * CH_NB + c], di);
+        __syncthreads();
+        // v[m][c] -= conj(U[i][m]) x_i[c]  for m > i, c <= i
+        for (int m = i + 1 + ty; m < nb; m += 16) {
+            const cplx u = Ud[i * CH_NB + m];
+            for (int c = tx; c <= i; c += 16) {
+                const cplx x = c == i ? c_make(di, 0.0) : Ud[i * CH_NB + c];
+                cplx v = Ud[m * CH_NB + c];
+                v.x -= u.x * x.x + u.y * x.y;
+                v.y -= u.x * x.y - u.y * x.x;
+                Ud[m * CH_NB + c] = v;
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = ty; i < nb; i += 16)
+        for (int k = tx; k < nb; k += 16) A[(int64_t)(j0 + i) * n + j0 + k] = Ud[i * CH_NB + k];
+}
+
+// U_J[:, cols] = W A_J[:, cols] for a chunk of TRSM_COLS trailing columns (or
+// right-hand sides).  grid (chunks, F), block 256.
+__global__ __launch_bounds__(256) void chol_trsm_kernel(cplx *__restrict__ R,
+                                                        cplx *__restrict__ P, int n, int D,
+                                                        int j0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx *W = reinterpret_cast<cplx *>(smem);            // CH_NB * CH_NB, lower incl. diagonal
+    cplx *As = W + CH_NB * CH_NB;                         // CH_NB * TRSM_COLS
+    const int f = blockIdx.y, tid = threadIdx.x;
     cplx *A = R + (int64_t)f * n * n;
     cplx *Z = P + (int64_t)f * n * D;
     const int nb = min(CH_NB, n - j0);
+    const int ntrail = n - j0 - nb;
+    const int c0 = blockIdx.x * TRSM_COLS;
 
     for (int idx = tid; idx < CH_NB * CH_NB; idx += blockDim.x) {
         const int i = idx / CH_NB, k = idx - i * CH_NB;
         cplx v = c_make(0.0, 0.0);
-        if (i < nb && k < nb && k >= i) v = A[(int64_t)(j0 + i) * n + j0 + k];
-        Ud[idx] = v;
-    }
-    __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        if (tid == 0) {
-            const double a = Ud[j * CH_NB + j].x;
-            double d = 0.0, di = 0.0;
-            if (a > 0.0 && isfinite(a)) {
-                d = sqrt(a);
-                di = 1.0 / d;
+        if (i < nb && k < nb) {
+            if (k < i) v = A[(int64_t)(j0 + i) * n + j0 + k];
+            else if (k == i) {
+                const double d = A[(int64_t)(j0 + i) * n + j0 + i].x;
+                v = c_make(d > 0.0 ? 1.0 / d : 0.0, 0.0);
             }
-            Ud[j * CH_NB + j] = c_make(d, 0.0);
-            dinv[j] = di;
         }
-        __syncthreads();
-        const double di = dinv[j];
-        for (int k = j + 1 + tid; k < nb; k += blockDim.x)
-            Ud[j * CH_NB + k] = c_scale(Ud[j * CH_NB + k], di);
-        __syncthreads();
-        const int r = nb - j - 1;
-        for (int it = tid; it < r * r; it += blockDim.x) {
-            const int ii = it / r, kk = it - ii * r;
-            if (kk < ii) continue;
-            const int i = j + 1 + ii, k = j + 1 + kk;
-            const cplx u = Ud[j * CH_NB + i], w = Ud[j * CH_NB + k];
-            cplx v = Ud[i * CH_NB + k];
-            v.x -= u.x * w.x + u.y * w.y;
-            v.y -= u.x * w.y - u.y * w.x;
-            Ud[i * CH_NB + k] = v;
-        }
-        __syncthreads();
+        W[idx] = v;
     }
-    for (int idx = tid; idx < nb * nb; idx += blockDim.x) {
-        const int i = idx / nb, k = idx - i * nb;
-        if (k >= i) A[(int64_t)(j0 + i) * n + j0 + k] = Ud[i * CH_NB + k];
-    }
-    // row panel: x = U_JJ^-H a for every trailing column and every right-hand side
-    const int ntrail = n - j0 - nb;
-    for (int c = tid; c < ntrail + D; c += blockDim.x) {
-        cplx *col;
-        int64_t stride;
+    const int cl = tid & (TRSM_COLS - 1), rg = tid / TRSM_COLS;   // 8 row groups
+    const int c = c0 + cl;
+    const bool cvalid = c < ntrail + D;
+    cplx *col = nullptr;
+    int64_t stride = 0;
+    if (cvalid) {
         if (c < ntrail) {
             col = A + (int64_t)j0 * n + j0 + nb + c;
             stride = n;
@@ -230,22 +279,17 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(cplx *__restrict__ R,
             col = Z + (int64_t)j0 * D + (c - ntrail);
             stride = D;
         }
-        cplx x[CH_NB];
+    }
+    for (int i = rg; i < CH_NB; i += 256 / TRSM_COLS)
+        As[i * TRSM_COLS + cl] = (cvalid && i < nb) ? col[i * stride] : c_make(0.0, 0.0);
+    __syncthreads();
+    constexpr int RPT = CH_NB / (256 / TRSM_COLS);   // rows per thread = 6
 #pragma unroll
-        for (int i = 0; i < CH_NB; ++i) {
-            if (i < nb) {
-                cplx v = col[i * stride];
-#pragma unroll
-                for (int k = 0; k < i; ++k) {
-                    const cplx u = Ud[k * CH_NB + i];   // conj(U[k][i]) * x[k]
-                    v.x -= u.x * x[k].x + u.y * x[k].y;
-                    v.y -= u.x * x[k].y - u.y * x[k].x;
-                }
-                v = c_scale(v, dinv[i]);
-                x[i] = v;
-                col[i * stride] = v;
-            }
-        }
+    for (int r = 0; r < RPT; ++r) {
+        const int i = rg * RPT + r;
+        cplx v = c_make(0.0, 0.0);
+        for (int k = 0; k <= i; ++k) c_fma(v, W[i * CH_NB + k], As[k * TRSM_COLS + cl]);
+        if (cvalid && i < nb) col[i * stride] = v;
     }
 }
 
@@ -271,6 +315,24 @@ __global__ __launch_bounds__(256) void chol_update_kernel(cplx *__restrict__ R,
     const cplx *zpanel = Z + (int64_t)j0 * D;
     const int ncols = tl.is_p ? D : n;
 
+    auto load_ops = [&](int ks, cplx (&a)[3], cplx (&b)[3]) {
+        const int kk = 4 * ks + lk;
+        const bool kv = kk < nb;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int ri = tl.row_off + 16 * m + li;
+            a[m] = (kv && ri < n) ? panel[(int64_t)kk * n + ri] : c_make(0.0, 0.0);
+            const int ci = tl.col_off + 16 * m + li;
+            b[m] = c_make(0.0, 0.0);
+            if (kv && ci < ncols)
+                b[m] = tl.is_p ? zpanel[(int64_t)kk * D + ci] : panel[(int64_t)kk * n + ci];
+        }
+    };
+
+    const int ksteps = (nb + 3) / 4;
+    cplx a_cur[3], b_cur[3], a_nxt[3], b_nxt[3];
+    load_ops(0, a_cur, b_cur);
+
     v4d acc_re[3][3], acc_im[3][3];
     // load C in fragment layout: col = li, row = lk + 4 * reg
 #pragma unroll
@@ -286,25 +348,16 @@ __global__ __launch_bounds__(256) void chol_update_kernel(cplx *__restrict__ R,
                 acc_re[a][b][reg] = v.x;
                 acc_im[a][b][reg] = v.y;
             }
-    const int ksteps = (nb + 3) / 4;
     for (int ks = 0; ks < ksteps; ++ks) {
-        const int kk = 4 * ks + lk;
-        const bool kv = kk < nb;
+        if (ks + 1 < ksteps) load_ops(ks + 1, a_nxt, b_nxt);
         double nar[3], nai[3], ai[3], br[3], bi[3];
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
-            const int ri = tl.row_off + 16 * m + li;
-            cplx a = c_make(0.0, 0.0);
-            if (kv && ri < n) a = panel[(int64_t)kk * n + ri];
-            nar[m] = -a.x;
-            nai[m] = -a.y;
-            ai[m] = a.y;
-            const int ci = tl.col_off + 16 * m + li;
-            cplx b = c_make(0.0, 0.0);
-            if (kv && ci < ncols)
-                b = tl.is_p ? zpanel[(int64_t)kk * D + ci] : panel[(int64_t)kk * n + ci];
-            br[m] = b.x;
-            bi[m] = b.y;
+            nar[m] = -a_cur[m].x;
+            nai[m] = -a_cur[m].y;
+            ai[m] = a_cur[m].y;
+            br[m] = b_cur[m].x;
+            bi[m] = b_cur[m].y;
         }
         // C -= conj(a) b :  re -= ar br + ai bi ;  im -= ar bi - ai br
 #pragma unroll
@@ -321,6 +374,11 @@ __global__ __launch_bounds__(256) void chol_update_kernel(cplx *__restrict__ R,
                 acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai[a], bi[b], acc_re[a][b], 0, 0, 0);
                 acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], br[b], acc_im[a][b], 0, 0, 0);
             }
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            a_cur[m] = a_nxt[m];
+            b_cur[m] = b_nxt[m];
+        }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -338,52 +396,45 @@ __global__ __launch_bounds__(256) void chol_update_kernel(cplx *__restrict__ R,
             }
 }
 
-// Blocked back substitution U G = Z, G overwrites Z.  grid (F), block 256.
-__global__ __launch_bounds__(256) void chol_backsolve_kernel(const cplx *__restrict__ R,
-                                                             cplx *__restrict__ P, int n, int D) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    cplx *Ud = reinterpret_cast<cplx *>(smem);        // CH_NB * CH_NB
-    cplx *S = Ud + CH_NB * CH_NB;                      // CH_NB * D
-    const int f = blockIdx.x, tid = threadIdx.x;
+// Blocked back substitution U G = Z, G overwrites Z:  G_J = W_J^H (Z_J - U_J,>J G_>J).
+// The right-hand sides are independent, so each workgroup takes BS_COLS of them:
+// grid (ceil(D / BS_COLS), F), block (BS_COLS * CH_NB) threads = one output each.
+constexpr int BS_COLS = 4;
+
+__global__ __launch_bounds__(BS_COLS * CH_NB) void chol_backsolve_kernel(
+    const cplx *__restrict__ R, cplx *__restrict__ P, int n, int D) {
+    __shared__ cplx S[CH_NB * BS_COLS];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const int dd = tid % BS_COLS, i = tid / BS_COLS;
+    const int d = blockIdx.x * BS_COLS + dd;
+    const bool dv = d < D;
     const cplx *A = R + (int64_t)f * n * n;
     cplx *Z = P + (int64_t)f * n * D;
     const int nblk = (n + CH_NB - 1) / CH_NB;
     for (int J = nblk - 1; J >= 0; --J) {
         const int j0 = J * CH_NB, nb = min(CH_NB, n - j0);
         __syncthreads();
-        for (int idx = tid; idx < nb * nb; idx += blockDim.x) {
-            const int i = idx / nb, k = idx - i * nb;
-            Ud[i * CH_NB + k] = k >= i ? A[(int64_t)(j0 + i) * n + j0 + k] : c_make(0.0, 0.0);
-        }
         // S = Z_J - U_J,>J G_>J
-        for (int idx = tid; idx < nb * D; idx += blockDim.x) {
-            const int i = idx / D, d = idx - i * D;
-            cplx v = Z[(int64_t)(j0 + i) * D + d];
+        cplx v = c_make(0.0, 0.0);
+        if (dv && i < nb) {
+            v = Z[(int64_t)(j0 + i) * D + d];
             const cplx *urow = A + (int64_t)(j0 + i) * n;
             for (int k = j0 + nb; k < n; ++k) {
                 const cplx u = urow[k], g = Z[(int64_t)k * D + d];
                 v.x -= u.x * g.x - u.y * g.y;
                 v.y -= u.x * g.y + u.y * g.x;
             }
-            S[idx] = v;
         }
+        S[i * BS_COLS + dd] = v;
         __syncthreads();
-        // triangular solve inside the block, one right-hand side per thread
-        if (tid < D) {
-            for (int i = nb - 1; i >= 0; --i) {
-                cplx v = S[i * D + tid];
-                for (int k = i + 1; k < nb; ++k) {
-                    const cplx u = Ud[i * CH_NB + k], g = S[k * D + tid];
-                    v.x -= u.x * g.x - u.y * g.y;
-                    v.y -= u.x * g.y + u.y * g.x;
-                }
-                const double d = Ud[i * CH_NB + i].x;
-                v = c_scale(v, d > 0.0 ? 1.0 / d : 0.0);
-                S[i * D + tid] = v;
-                Z[(int64_t)(j0 + i) * D + tid] = v;
-            }
+        // G_J[i] = sum_{k >= i} conj(W[k][i]) S[k],  W[k][k] = 1 / U[k][k]
+        if (dv && i < nb) {
+            const double diag = A[(int64_t)(j0 + i) * n + j0 + i].x;
+            cplx g = c_scale(S[i * BS_COLS + dd], diag > 0.0 ? 1.0 / diag : 0.0);
+            for (int k = i + 1; k < nb; ++k)
+                c_cfma(g, A[(int64_t)(j0 + k) * n + j0 + i], S[k * BS_COLS + dd]);
+            Z[(int64_t)(j0 + i) * D + d] = g;
         }
-        __syncthreads();
     }
 }
 
@@ -527,7 +578,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     const int padf = corr_padf(D);
     const size_t corr_lds = sizeof(cplx) * (size_t)(CORR_KT + c + padf) * D + sizeof(double) * CORR_KT;
     const size_t panel_lds = sizeof(cplx) * CH_NB * CH_NB + sizeof(double) * CH_NB;
-    const size_t back_lds = sizeof(cplx) * (CH_NB * CH_NB + (size_t)CH_NB * D);
+    const size_t trsm_lds = sizeof(cplx) * (CH_NB * CH_NB + CH_NB * TRSM_COLS);
     const int ntq = 256 / D;
     const int tc = ntq * APPLY_TB;
     const size_t apply_lds = sizeof(cplx) * ((size_t)n * D + (size_t)(tc + c) * D);
@@ -555,24 +606,34 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                                ctx->stream, Y, w, T, D, n, c, padf, tiles_dev, ntiles, R, P);
             GSS_LAUNCH_CHECK(ctx, "wpe_corr_kernel");
         }
-        {
-            GSS_PROF(ctx, "wpe_solve");
-            const int nblk = (n + CH_NB - 1) / CH_NB;
-            for (int J = 0; J < nblk; ++J) {
-                const int j0 = J * CH_NB, nb = std::min(CH_NB, n - j0);
-                hipLaunchKernelGGL(chol_panel_kernel, dim3(F), dim3(256), panel_lds, ctx->stream,
-                                   R, P, n, D, j0);
-                GSS_LAUNCH_CHECK(ctx, "chol_panel_kernel");
-                const int nupd = upd_count[J];
-                if (nupd > 0) {
-                    hipLaunchKernelGGL(chol_update_kernel, dim3((nupd + 3) / 4, F), dim3(256), 0,
-                                       ctx->stream, R, P, n, D, j0, nb, upd_dev + upd_start[J],
-                                       nupd);
-                    GSS_LAUNCH_CHECK(ctx, "chol_update_kernel");
-                }
+        const int nblk = (n + CH_NB - 1) / CH_NB;
+        for (int J = 0; J < nblk; ++J) {
+            const int j0 = J * CH_NB, nb = std::min(CH_NB, n - j0);
+            {
+                GSS_PROF(ctx, "wpe_chol_diag");
+                hipLaunchKernelGGL(chol_diag_kernel, dim3(F), dim3(256), panel_lds, ctx->stream, R, n,
+                                   j0);
+                GSS_LAUNCH_CHECK(ctx, "chol_diag_kernel");
             }
-            hipLaunchKernelGGL(chol_backsolve_kernel, dim3(F), dim3(256), back_lds, ctx->stream, R,
-                               P, n, D);
+            {
+                GSS_PROF(ctx, "wpe_chol_trsm");
+                const int ncol = n - j0 - nb + D;
+                hipLaunchKernelGGL(chol_trsm_kernel, dim3((ncol + TRSM_COLS - 1) / TRSM_COLS, F),
+                                   dim3(256), trsm_lds, ctx->stream, R, P, n, D, j0);
+                GSS_LAUNCH_CHECK(ctx, "chol_trsm_kernel");
+            }
+            const int nupd = upd_count[J];
+            if (nupd > 0) {
+                GSS_PROF(ctx, "wpe_chol_update");
+                hipLaunchKernelGGL(chol_update_kernel, dim3((nupd + 3) / 4, F), dim3(256), 0,
+                                   ctx->stream, R, P, n, D, j0, nb, upd_dev + upd_start[J], nupd);
+                GSS_LAUNCH_CHECK(ctx, "chol_update_kernel");
+            }
+        }
+        {
+            GSS_PROF(ctx, "wpe_backsolve");
+            hipLaunchKernelGGL(chol_backsolve_kernel, dim3((D + BS_COLS - 1) / BS_COLS, F),
+                               dim3(BS_COLS * CH_NB), 0, ctx->stream, R, P, n, D);
             GSS_LAUNCH_CHECK(ctx, "chol_backsolve_kernel");
         }
         {

@@ -35,9 +35,12 @@ def kernel_work(name, *, F, T, D, K, taps, N):
         return dict(flops=F * 8.0 * D * n * T, bytes=2 * BY + 16.0 * F * n * D, bound='mfma')
     if name == 'wpe_power':
         return dict(flops=F * T * 3.0 * D, bytes=BY + 8.0 * F * T, bound='hbm')
-    if name == 'em_step':
-        # per (f, t, k): 8 D^2 (quadratic form) + 4 D^2 (Hermitian accumulate)
-        return dict(flops=12.0 * D * D * K * F * T, bytes=BY, bound='mfma')
+    if name == 'em_estep':
+        # per (f, t, k): 8 D^2 (quadratic form  y^H B_k^-1 y)
+        return dict(flops=8.0 * D * D * K * F * T, bytes=BY + 8.0 * F * K * T, bound='mfma')
+    if name == 'em_mstep':
+        # per (f, t, k): 4 D^2 (Hermitian outer-product accumulate)
+        return dict(flops=4.0 * D * D * K * F * T, bytes=BY + 8.0 * F * K * T, bound='mfma')
     if name == 'em_predict':
         return dict(flops=8.0 * D * D * K * F * T, bytes=BY + 8.0 * F * K * T, bound='mfma')
     if name == 'em_eig':
