@@ -368,35 +368,91 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
     }
 }
 
-// In-place lower Cholesky of the Hermitian positive definite n x n matrix A (LDS,
-// leading dimension ld) by one wave; returns false (wave-uniform) on a
-// non-positive pivot.  Only the lower triangle is referenced / written.
+// ------------------------------------------------------------------ model update
+// Single-wave linear algebra on one D x D matrix in LDS (leading dimension ld).
+// Lane grid for 2-D updates: (ri, ci) = (lane >> 3, lane & 7).
+
+// In-place lower Cholesky A = L L^H; only the lower triangle is referenced and
+// written.  Returns false (wave-uniform) on a non-positive pivot.
 __device__ inline bool cholesky_lower_wave(cplx *A, int n, int ld, int lane) {
+    const int ri = lane >> 3, ci = lane & 7;
     for (int j = 0; j < n; ++j) {
         const double ajj = A[j * ld + j].x;
         if (!(ajj > 0.0) || !isfinite(ajj)) return false;
         const double d = sqrt(ajj), dinv = 1.0 / d;
         __syncthreads();
-        for (int i = j + lane; i < n; i += 64) {
-            if (i == j) A[j * ld + j] = c_make(d, 0.0);
-            else A[i * ld + j] = c_scale(A[i * ld + j], dinv);
-        }
+        const int i = j + 1 + lane;
+        if (i < n) A[i * ld + j] = c_scale(A[i * ld + j], dinv);
+        if (lane == 0) A[j * ld + j] = c_make(d, 0.0);
         __syncthreads();
         // trailing update of the lower triangle: A[i][k] -= L[i][j] conj(L[k][j]), j < k <= i
         const int r = n - j - 1;
-        for (int it = lane; it < r * r; it += 64) {
-            const int ii = it / r, kk = it - ii * r;
-            if (kk > ii) continue;
-            const int i = j + 1 + ii, k = j + 1 + kk;
-            const cplx li = A[i * ld + j], lk = A[k * ld + j];
-            cplx v = A[i * ld + k];
-            v.x -= li.x * lk.x + li.y * lk.y;
-            v.y -= li.y * lk.x - li.x * lk.y;
-            A[i * ld + k] = v;
+        for (int ii = ri; ii < r; ii += 8) {
+            const cplx li = A[(j + 1 + ii) * ld + j];
+            for (int kk = ci; kk <= ii; kk += 8) {
+                const cplx lk = A[(j + 1 + kk) * ld + j];
+                cplx v = A[(j + 1 + ii) * ld + j + 1 + kk];
+                v.x -= li.x * lk.x + li.y * lk.y;
+                v.y -= li.y * lk.x - li.x * lk.y;
+                A[(j + 1 + ii) * ld + j + 1 + kk] = v;
+            }
         }
+    }
+    __syncthreads();
+    return true;
+}
+
+// In-place inverse of the lower-triangular L (n <= 64): column j of L^-1 is
+//   Linv[j][j] = 1 / L[j][j],   Linv[i][j] = -Linv[j][j] * sum_{k=j+1..i} Linv[i][k] L[k][j]
+// processed for j = n-1 .. 0 so that the trailing block is already inverted.
+__device__ inline void invert_lower_wave(cplx *A, int n, int ld, int lane) {
+    for (int j = n - 1; j >= 0; --j) {
+        const double ajj = 1.0 / A[j * ld + j].x;
+        const int i = j + 1 + lane;
+        cplx x = c_make(0.0, 0.0);
+        if (i < n)
+            for (int k = j + 1; k <= i; ++k) c_fma(x, A[i * ld + k], A[k * ld + j]);
+        __syncthreads();
+        if (i < n) A[i * ld + j] = c_make(-ajj * x.x, -ajj * x.y);
+        if (lane == 0) A[j * ld + j] = c_make(ajj, 0.0);
         __syncthreads();
     }
-    return true;
+}
+
+__device__ __forceinline__ void tri_unpack(int e, int D, int &d1, int &d2) {
+    d1 = 0;
+    int rem = e;
+    while (rem >= D - d1) {
+        rem -= D - d1;
+        ++d1;
+    }
+    d2 = d1 + rem;
+}
+
+// B_k = D * (sum over chunks of the partial sums) / max(sum gamma, tiny), lower
+// triangle (and the mirrored upper one if `full`) into LDS; returns tr(B).
+__device__ inline double load_covariance(const cplx *__restrict__ Bp, int nch, int D, int K, int k,
+                                         int f, double den, double shift, bool full, cplx *A,
+                                         int ld, int lane) {
+    const int NE = tri_count(D);
+    double tr = 0.0;
+    for (int e = lane; e < NE; e += 64) {
+        int d1, d2;
+        tri_unpack(e, D, d1, d2);
+        cplx v = c_make(0.0, 0.0);
+        for (int c = 0; c < nch; ++c)
+            v = c_add(v, Bp[(((int64_t)f * nch + c) * K + k) * NE + e]);
+        v.x = ((double)D * v.x) / den;
+        v.y = ((double)D * v.y) / den;
+        if (d1 == d2) {
+            v.y = 0.0;
+            tr += v.x;
+            v.x -= shift;
+        }
+        A[d2 * ld + d1] = c_conj(v);            // lower triangle: B[d2][d1] = conj(B[d1][d2])
+        if (full) A[d1 * ld + d2] = v;
+    }
+    return wave_sum(tr);
 }
 
 // grid (K, F), block 64 (one wave per class matrix).
@@ -407,153 +463,121 @@ __device__ inline bool cholesky_lower_wave(cplx *A, int n, int ld, int lane) {
 // covariance by a constant that the next normalisation removes again.  So whenever
 // NO eigenvalue is floored -- lambda_min > 1e-10 lambda_max, certified here by a
 // successful Cholesky factorisation of B - 1e-10 tr(B) I (tr B >= lambda_max) --
-// B^-1 and ln det B from a Cholesky factorisation give the same posteriors, and
-// the eigendecomposition is only run for matrices that fail the certificate.
-__global__ __launch_bounds__(64) void em_eig_kernel(const cplx *__restrict__ Bp,
-                                                    const double *__restrict__ Sg, int nch, int D,
-                                                    int K, int64_t T, double eig_floor,
-                                                    int force_eigh, cplx *__restrict__ Mq,
-                                                    double *__restrict__ logdet,
-                                                    double *__restrict__ pi,
-                                                    int *__restrict__ slow_count) {
+// B^-1 and ln det B from a Cholesky factorisation give the same posteriors.
+// Matrices that fail the certificate are flagged for em_eigh_kernel.
+__global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp,
+                                                     const double *__restrict__ Sg, int nch, int D,
+                                                     int K, int64_t T, double eig_floor,
+                                                     int force_eigh, cplx *__restrict__ Mq,
+                                                     double *__restrict__ logdet,
+                                                     double *__restrict__ pi,
+                                                     int *__restrict__ need_eigh) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ld = D + (D & 1);
+    const int NE = tri_count(D);
+    cplx *A = reinterpret_cast<cplx *>(smem);   // D * ld
+    const int k = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+
+    double sg = 0.0;
+    for (int c = 0; c < nch; ++c) sg += Sg[((int64_t)f * nch + c) * K + k];
+    const double den = fmax(sg, GSS_TINY);
+    if (lane == 0) pi[f * K + k] = sg / (double)T;
+
+    // certificate: B - floor * tr(B) * I positive definite
+    double tr = load_covariance(Bp, nch, D, K, k, f, den, 0.0, false, A, ld, lane);
+    bool fast = !force_eigh && tr > 0.0 && isfinite(tr);
+    if (fast) {
+        __syncthreads();
+        for (int i = lane; i < D; i += 64) A[i * ld + i].x -= eig_floor * tr;
+        __syncthreads();
+        fast = cholesky_lower_wave(A, D, ld, lane);
+    }
+    if (fast) {
+        __syncthreads();
+        load_covariance(Bp, nch, D, K, k, f, den, 0.0, false, A, ld, lane);
+        __syncthreads();
+        fast = cholesky_lower_wave(A, D, ld, lane);   // B itself is PD a fortiori
+    }
+    if (lane == 0) need_eigh[f * K + k] = fast ? 0 : 1;
+    if (!fast) return;
+    double ldv = 0.0;
+    for (int i = lane; i < D; i += 64) ldv += 2.0 * log(A[i * ld + i].x);
+    ldv = wave_sum(ldv);
+    __syncthreads();
+    invert_lower_wave(A, D, ld, lane);
+    // B^-1 = Linv^H Linv :  (d1,d2) = sum_{j >= d2} conj(Linv[j][d1]) Linv[j][d2]
+    for (int e = lane; e < NE; e += 64) {
+        int d1, d2;
+        tri_unpack(e, D, d1, d2);
+        cplx v = c_make(0.0, 0.0);
+        for (int j = d2; j < D; ++j) c_cfma(v, A[j * ld + d1], A[j * ld + d2]);
+        if (d1 == d2) {
+            v.y = 0.0;
+        } else {
+            v.x *= 2.0;
+            v.y *= 2.0;
+        }
+        Mq[((int64_t)f * NE + e) * K + k] = v;
+    }
+    if (lane == 0) logdet[f * K + k] = ldv;
+}
+
+// Eigendecomposition path for the flagged matrices: eigenvalues / max, floor, then
+// B^-1 = V diag(1/lambda) V^H and ln det = sum ln lambda, exactly as the reference.
+__global__ __launch_bounds__(64) void em_eigh_kernel(const cplx *__restrict__ Bp,
+                                                     const double *__restrict__ Sg, int nch, int D,
+                                                     int K, double eig_floor,
+                                                     const int *__restrict__ need_eigh,
+                                                     cplx *__restrict__ Mq,
+                                                     double *__restrict__ logdet) {
+    const int k = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    if (!need_eigh[f * K + k]) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = D + (D & 1);
     const int NE = tri_count(D);
     cplx *A = reinterpret_cast<cplx *>(smem);   // m * m
     cplx *V = A + m * m;                         // m * m
     double *lam = reinterpret_cast<double *>(V + m * m);   // m
-    const int k = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
 
     double sg = 0.0;
     for (int c = 0; c < nch; ++c) sg += Sg[((int64_t)f * nch + c) * K + k];
     const double den = fmax(sg, GSS_TINY);
-
     for (int idx = lane; idx < m * m; idx += 64) A[idx] = c_make(0.0, 0.0);
     __syncthreads();
-    double tr = 0.0;
+    load_covariance(Bp, nch, D, K, k, f, den, 0.0, true, A, m, lane);
+    __syncthreads();
+    jacobi_eigh_wave(A, V, m, lane, 20);
+    double lmax = -INFINITY;
+    for (int i = lane; i < D; i += 64) lmax = fmax(lmax, A[i * m + i].x);
+    lmax = wave_max(lmax);
+    double ldv = 0.0;
+    for (int i = lane; i < D; i += 64) {
+        double l = A[i * m + i].x / fmax(lmax, GSS_TINY);
+        l = fmax(l, eig_floor);
+        lam[i] = 1.0 / l;
+        ldv += log(l);
+    }
+    ldv = wave_sum(ldv);
+    __syncthreads();
     for (int e = lane; e < NE; e += 64) {
-        int d1 = 0, rem = e;
-        while (rem >= D - d1) {
-            rem -= D - d1;
-            ++d1;
-        }
-        const int d2 = d1 + rem;
+        int d1, d2;
+        tri_unpack(e, D, d1, d2);
         cplx v = c_make(0.0, 0.0);
-        for (int c = 0; c < nch; ++c)
-            v = c_add(v, Bp[(((int64_t)f * nch + c) * K + k) * NE + e]);
-        v.x = ((double)D * v.x) / den;
-        v.y = ((double)D * v.y) / den;
+        for (int j = 0; j < D; ++j) {
+            const cplx a = V[d1 * m + j], b = V[d2 * m + j];
+            const double il = lam[j];
+            v.x += il * (a.x * b.x + a.y * b.y);
+            v.y += il * (a.y * b.x - a.x * b.y);
+        }
         if (d1 == d2) {
             v.y = 0.0;
-            tr += v.x;
+        } else {
+            v.x *= 2.0;
+            v.y *= 2.0;
         }
-        A[d1 * m + d2] = v;
-        A[d2 * m + d1] = c_conj(v);
+        Mq[((int64_t)f * NE + e) * K + k] = v;
     }
-    tr = wave_sum(tr);
-    __syncthreads();
-
-    bool fast = false;
-    if (!force_eigh && tr > 0.0 && isfinite(tr)) {
-        // certificate: B - floor * tr(B) * I positive definite  (work in V)
-        const double shift = eig_floor * tr;
-        for (int idx = lane; idx < D * D; idx += 64) {
-            const int i = idx / D, j = idx - i * D;
-            cplx v = A[i * m + j];
-            if (i == j) v.x -= shift;
-            V[i * m + j] = v;
-        }
-        __syncthreads();
-        fast = cholesky_lower_wave(V, D, m, lane);
-        __syncthreads();
-    }
-    if (fast) {
-        // factor B itself (it is positive definite a fortiori)
-        for (int idx = lane; idx < D * D; idx += 64) {
-            const int i = idx / D, j = idx - i * D;
-            V[i * m + j] = A[i * m + j];
-        }
-        __syncthreads();
-        fast = cholesky_lower_wave(V, D, m, lane);
-        __syncthreads();
-    }
-    double ld = 0.0;
-    if (fast) {
-        // ln det B = 2 sum ln L_ii ;  Linv = L^-1 (lower), one column per lane, into A
-        for (int i = lane; i < D; i += 64) ld += 2.0 * log(V[i * m + i].x);
-        ld = wave_sum(ld);
-        __syncthreads();
-        if (lane < D) {
-            const int c = lane;
-            for (int i = 0; i < c; ++i) A[i * m + c] = c_make(0.0, 0.0);
-            A[c * m + c] = c_make(1.0 / V[c * m + c].x, 0.0);
-            for (int i = c + 1; i < D; ++i) {
-                cplx acc = c_make(0.0, 0.0);
-                for (int j = c; j < i; ++j) c_fma(acc, V[i * m + j], A[j * m + c]);
-                const double dinv = 1.0 / V[i * m + i].x;
-                A[i * m + c] = c_make(-acc.x * dinv, -acc.y * dinv);
-            }
-        }
-        __syncthreads();
-        // B^-1 = Linv^H Linv :  (d1,d2) = sum_{j >= d2} conj(Linv[j][d1]) Linv[j][d2]
-        for (int e = lane; e < NE; e += 64) {
-            int d1 = 0, rem = e;
-            while (rem >= D - d1) {
-                rem -= D - d1;
-                ++d1;
-            }
-            const int d2 = d1 + rem;
-            cplx v = c_make(0.0, 0.0);
-            for (int j = d2; j < D; ++j) c_cfma(v, A[j * m + d1], A[j * m + d2]);
-            if (d1 == d2) {
-                v.y = 0.0;
-            } else {
-                v.x *= 2.0;
-                v.y *= 2.0;
-            }
-            Mq[((int64_t)f * NE + e) * K + k] = v;
-        }
-    } else {
-        if (lane == 0 && slow_count) atomicAdd(slow_count, 1);
-        jacobi_eigh_wave(A, V, m, lane, 20);
-        double lmax = -INFINITY;
-        for (int i = lane; i < D; i += 64) lmax = fmax(lmax, A[i * m + i].x);
-        lmax = wave_max(lmax);
-        for (int i = lane; i < D; i += 64) {
-            double l = A[i * m + i].x / fmax(lmax, GSS_TINY);
-            l = fmax(l, eig_floor);
-            lam[i] = 1.0 / l;
-            ld += log(l);
-        }
-        ld = wave_sum(ld);
-        __syncthreads();
-        for (int e = lane; e < NE; e += 64) {
-            int d1 = 0, rem = e;
-            while (rem >= D - d1) {
-                rem -= D - d1;
-                ++d1;
-            }
-            const int d2 = d1 + rem;
-            cplx v = c_make(0.0, 0.0);
-            for (int j = 0; j < D; ++j) {
-                const cplx a = V[d1 * m + j], b = V[d2 * m + j];
-                const double il = lam[j];
-                v.x += il * (a.x * b.x + a.y * b.y);
-                v.y += il * (a.y * b.x - a.x * b.y);
-            }
-            if (d1 == d2) {
-                v.y = 0.0;
-            } else {
-                v.x *= 2.0;
-                v.y *= 2.0;
-            }
-            Mq[((int64_t)f * NE + e) * K + k] = v;
-        }
-    }
-    if (lane == 0) {
-        logdet[f * K + k] = ld;
-        pi[f * K + k] = sg / (double)T;
-    }
+    if (lane == 0) logdet[f * K + k] = ldv;
 }
 
 size_t em_estep_lds(int D, int K) {
@@ -660,6 +684,7 @@ size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K) {
     b += align_up(sizeof(double) * (size_t)F * K * T);           // W
     b += align_up(sizeof(cplx) * (size_t)F * nch * K * NE);      // Bp
     b += align_up(sizeof(double) * (size_t)F * nch * K);         // Sg
+    b += align_up(sizeof(int) * (size_t)F * K);                  // need_eigh
     return b + 4096;
 }
 
@@ -689,14 +714,25 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     GSS_REQUIRE(ctx, em_estep_lds(D, K) <= 160 * 1024 && wcov_lds_layout(D, K).total <= 160 * 1024,
                 GSS_ERR_UNSUPPORTED, "cacgmm: D=%d K=%d LDS", D, K);
     const int m = D + (D & 1);
-    const size_t eig_lds = (sizeof(cplx) * 2 * m * m + sizeof(double) * m + 15) / 16 * 16;
+    const size_t chol_lds = (sizeof(cplx) * (size_t)D * m + 15) / 16 * 16;
+    const size_t eigh_lds = (sizeof(cplx) * 2 * m * m + sizeof(double) * m + 15) / 16 * 16;
     const int force_eigh = getenv("GSS_FORCE_EIGH") != nullptr;
+    int *need_eigh = arena_alloc_t<int>(ctx, (size_t)F * K);
+    GSS_REQUIRE(ctx, need_eigh, GSS_ERR_NOMEM, "cacgmm workspace");
 
     auto eig = [&]() -> int {
-        GSS_PROF(ctx, "em_eig");
-        hipLaunchKernelGGL(em_eig_kernel, dim3(K, F), dim3(64), eig_lds, ctx->stream, a.Bp, a.Sg,
-                           a.nch, D, K, T, 1e-10, force_eigh, Mq, logdet, pi, (int *)nullptr);
-        GSS_LAUNCH_CHECK(ctx, "em_eig_kernel");
+        {
+            GSS_PROF(ctx, "em_chol");
+            hipLaunchKernelGGL(em_chol_kernel, dim3(K, F), dim3(64), chol_lds, ctx->stream, a.Bp,
+                               a.Sg, a.nch, D, K, T, 1e-10, force_eigh, Mq, logdet, pi, need_eigh);
+            GSS_LAUNCH_CHECK(ctx, "em_chol_kernel");
+        }
+        {
+            GSS_PROF(ctx, "em_eigh");
+            hipLaunchKernelGGL(em_eigh_kernel, dim3(K, F), dim3(64), eigh_lds, ctx->stream, a.Bp,
+                               a.Sg, a.nch, D, K, 1e-10, need_eigh, Mq, logdet);
+            GSS_LAUNCH_CHECK(ctx, "em_eigh_kernel");
+        }
         return GSS_OK;
     };
 

@@ -440,48 +440,109 @@ __global__ __launch_bounds__(BS_COLS * CH_NB) void chol_backsolve_kernel(
 
 // ------------------------------------------------------------------ apply
 // X[t][d] = Y[t][d] - sum_r conj(G[r][d]) Yflat[(t - c) D + r]
-constexpr int APPLY_TB = 4;
+// As a GEMM per frequency: out(frames x channels) = U^T conj(G), K = n = taps * D,
+// on the f64 MFMA.  A[i = frame][k = r] comes from the LDS copy of the sliding
+// window, B[k = r][j = d] straight from G in global memory (L2 resident, shared
+// by all workgroups of a frequency), double-buffered in registers.
+// grid (ceil(T / 128), F), block 256: each wave owns 32 frames x 32 channel slots.
+constexpr int AP_WAVE_FRAMES = 32;
+constexpr int AP_WG_FRAMES = 4 * AP_WAVE_FRAMES;
 
 __global__ __launch_bounds__(256) void wpe_apply_kernel(const cplx *__restrict__ Y,
                                                         const cplx *__restrict__ G, int64_t T,
-                                                        int D, int n, int c, int tc,
+                                                        int D, int n, int c,
                                                         cplx *__restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cplx *Gs = reinterpret_cast<cplx *>(smem);   // n * D
-    cplx *S = Gs + n * D;                        // (tc + c) * D
+    cplx *S = reinterpret_cast<cplx *>(smem);   // (AP_WG_FRAMES + c + 2) * D
     const int f = blockIdx.y;
-    const int64_t t0 = (int64_t)blockIdx.x * tc;
+    const int64_t t0 = (int64_t)blockIdx.x * AP_WG_FRAMES;
     const cplx *Yf = Y + (int64_t)f * T * D;
     const cplx *Gf = G + (int64_t)f * n * D;
-    for (int idx = threadIdx.x; idx < n * D; idx += blockDim.x) Gs[idx] = Gf[idx];
+    const int frames_lds = AP_WG_FRAMES + c + 2;
     const int64_t fr0 = t0 - c;
-    for (int idx = threadIdx.x; idx < (tc + c) * D; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < frames_lds * D; idx += blockDim.x) {
         const int64_t fr = fr0 + idx / D;
         cplx v = c_make(0.0, 0.0);
         if (fr >= 0 && fr < T) v = Yf[fr0 * D + idx];
         S[idx] = v;
     }
     __syncthreads();
-    const int ntq = blockDim.x / D;
-    const int d = threadIdx.x % D, tq = threadIdx.x / D;
-    if (tq >= ntq) return;
-    cplx acc[APPLY_TB];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int wf0 = wave * AP_WAVE_FRAMES;       // first frame of this wave, tile relative
+    const int nct = (D + 15) / 16;                // channel tiles (<= 2)
+
+    v4d acc_re[2][2], acc_im[2][2];
 #pragma unroll
-    for (int b = 0; b < APPLY_TB; ++b) acc[b] = c_make(0.0, 0.0);
-    const cplx *Sb = S + tq * APPLY_TB * D;
-    for (int r = 0; r < n; ++r) {
-        const cplx g = Gs[r * D + d];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < APPLY_TB; ++b) c_cfma(acc[b], g, Sb[b * D + r]);
-    }
-#pragma unroll
-    for (int b = 0; b < APPLY_TB; ++b) {
-        const int64_t t = t0 + tq * APPLY_TB + b;
-        if (t < T) {
-            const cplx y = S[(tq * APPLY_TB + b + c) * D + d];
-            X[((int64_t)f * T + t) * D + d] = c_sub(y, acc[b]);
+        for (int b = 0; b < 2; ++b) {
+            acc_re[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+            acc_im[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
         }
+    auto load_b = [&](int ks, cplx (&g)[2]) {
+        const int r = 4 * ks + lk;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int d = 16 * b + li;
+            g[b] = (r < n && d < D) ? Gf[(int64_t)r * D + d] : c_make(0.0, 0.0);
+        }
+    };
+    const int ksteps = (n + 3) / 4;
+    cplx g_cur[2], g_nxt[2];
+    load_b(0, g_cur);
+    for (int ks = 0; ks < ksteps; ++ks) {
+        if (ks + 1 < ksteps) load_b(ks + 1, g_nxt);
+        const int r = 4 * ks + lk;
+        double ur[2], ui[2], gr[2], gi[2], ngi[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const cplx u = S[(wf0 + 16 * a + li) * D + r];
+            ur[a] = u.x;
+            ui[a] = u.y;
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            gr[b] = g_cur[b].x;
+            gi[b] = g_cur[b].y;
+            ngi[b] = -g_cur[b].y;
+        }
+        // u * conj(g)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (b >= nct) continue;
+                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[a], gr[b], acc_re[a][b], 0, 0, 0);
+                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui[a], gr[b], acc_im[a][b], 0, 0, 0);
+            }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (b >= nct) continue;
+                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui[a], gi[b], acc_re[a][b], 0, 0, 0);
+                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[a], ngi[b], acc_im[a][b], 0, 0, 0);
+            }
+        g_cur[0] = g_nxt[0];
+        g_cur[1] = g_nxt[1];
     }
+    // C/D fragment: col = li (channel), row = lk + 4 * reg (frame)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int fl = wf0 + 16 * a + lk + 4 * reg;
+                const int d = 16 * b + li;
+                const int64_t t = t0 + fl;
+                if (d < D && t < T) {
+                    const cplx y = S[(fl + c) * D + d];
+                    X[((int64_t)f * T + t) * D + d] =
+                        c_make(y.x - acc_re[a][b][reg], y.y - acc_im[a][b][reg]);
+                }
+            }
 }
 
 // ------------------------------------------------------------------ MFMA layout self-test
@@ -579,9 +640,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     const size_t corr_lds = sizeof(cplx) * (size_t)(CORR_KT + c + padf) * D + sizeof(double) * CORR_KT;
     const size_t panel_lds = sizeof(cplx) * CH_NB * CH_NB + sizeof(double) * CH_NB;
     const size_t trsm_lds = sizeof(cplx) * (CH_NB * CH_NB + CH_NB * TRSM_COLS);
-    const int ntq = 256 / D;
-    const int tc = ntq * APPLY_TB;
-    const size_t apply_lds = sizeof(cplx) * ((size_t)n * D + (size_t)(tc + c) * D);
+    const size_t apply_lds = sizeof(cplx) * (size_t)(AP_WG_FRAMES + c + 2) * D;
     GSS_REQUIRE(ctx, corr_lds <= 160 * 1024 && apply_lds <= 160 * 1024, GSS_ERR_UNSUPPORTED,
                 "wpe: taps=%d D=%d needs more LDS than a CU has", taps, D);
     if (apply_lds > 64 * 1024)
@@ -638,8 +697,9 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         }
         {
             GSS_PROF(ctx, "wpe_apply");
-            hipLaunchKernelGGL(wpe_apply_kernel, dim3((unsigned)((T + tc - 1) / tc), F), dim3(256),
-                               apply_lds, ctx->stream, Y, P, T, D, n, c, tc, X);
+            hipLaunchKernelGGL(wpe_apply_kernel,
+                               dim3((unsigned)((T + AP_WG_FRAMES - 1) / AP_WG_FRAMES), F),
+                               dim3(256), apply_lds, ctx->stream, Y, P, T, D, n, c, X);
             GSS_LAUNCH_CHECK(ctx, "wpe_apply_kernel");
         }
     }

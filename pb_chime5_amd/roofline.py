@@ -43,7 +43,7 @@ def kernel_work(name, *, F, T, D, K, taps, N):
         return dict(flops=4.0 * D * D * K * F * T, bytes=BY + 8.0 * F * K * T, bound='mfma')
     if name == 'em_predict':
         return dict(flops=8.0 * D * D * K * F * T, bytes=BY + 8.0 * F * K * T, bound='mfma')
-    if name == 'em_eig':
+    if name in ('em_eig', 'em_chol'):
         # Jacobi eigh ~ 2e6 flop at D = 24, scaled ~ D^3
         return dict(flops=F * K * 2.0e6 * (D / 24.0) ** 3, bytes=16.0 * F * K * D * D * 2,
                     bound='mfma')
