@@ -184,7 +184,9 @@ def main():
         traffic_file = REPO / 'profiles' / 'traffic.json'
         if roof is not None and traffic_file.exists():
             try:
-                roof['traffic'] = json.loads(traffic_file.read_text()).get(dominant)
+                roof['traffic'] = json.loads(traffic_file.read_text()).get(dominant, {}).get('bytes')
+                roof['traffic_note'] = ('HBM-side bytes per launch from profiles/traffic.json '
+                                        '(rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)')
             except Exception:
                 pass
         line = {
