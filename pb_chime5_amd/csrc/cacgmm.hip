@@ -41,7 +41,7 @@ struct EmArgs {
     double *Sg;             // (F,NCH,K)
     double *gamma;          // (F,K,T)   MODE_PREDICT only
     int64_t T;
-    int D, NE, nch, chunk_frames;
+    int F, D, NE, nch, chunk_frames;
     int masked;             // multiply the activity mask into the posteriors
     double aff_eps;         // clip, 0 = none
 };
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void em_estep_kernel(EmArgs a, const cplx *__r
     double *pis = ldet + K;                                          // K
     double *vvS = qpart;   // the partial sums are dead once lp / qq are written
 
-    const int f = blockIdx.y, chunk = blockIdx.x;
+    int f, chunk;
+    if (!xcd_group_map(a.nch, a.F, f, chunk)) return;
     const int tid = threadIdx.x;
     const int tl = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, uniform
@@ -263,9 +264,9 @@ __host__ __device__ inline WcovLds wcov_lds_layout(int D, int KW) {
 
 template <int KW, bool NORMALISE>
 __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
-                                                   const double *__restrict__ W, int64_t T, int D,
-                                                   int NE, int nch, int chunk_frames,
-                                                   cplx *__restrict__ part) {
+                                                   const double *__restrict__ W, int F,
+                                                   int64_t T, int D, int NE, int nch,
+                                                   int chunk_frames, cplx *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WcovLds L = wcov_lds_layout(D, KW);
     const int Dp = L.Dp;
@@ -274,7 +275,9 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
     double *scratch = reinterpret_cast<double *>(smem + L.scratch);
     unsigned char *blk = reinterpret_cast<unsigned char *>(smem + L.blk);
 
-    const int f = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    int f, chunk;
+    if (!xcd_group_map(nch, F, f, chunk)) return;
+    const int tid = threadIdx.x;
     const int tl = tid & 63, g = tid >> 6;
     const int64_t c0 = (int64_t)chunk * chunk_frames;
     const int64_t c1 = c0 + chunk_frames < T ? c0 + chunk_frames : T;
@@ -609,7 +612,7 @@ int raise_lds_limit(gss_ctx *ctx, Kern kern, size_t lds) {
 template <int K>
 int launch_estep(gss_ctx *ctx, int mode, const EmArgs &a, const cplx *Mq, int F) {
     const size_t lds = em_estep_lds(a.D, K);
-    dim3 grid(a.nch, F), block(256);
+    dim3 grid(xcd_grid(a.nch, F)), block(256);
     if (mode == MODE_FIRST) {
         GSS_PROF(ctx, "em_estep");
         hipLaunchKernelGGL((em_estep_kernel<K, MODE_FIRST>), grid, block, 0, ctx->stream, a, Mq);
@@ -632,8 +635,8 @@ int launch_mstep(gss_ctx *ctx, const EmArgs &a, int F) {
     const size_t lds = wcov_lds_layout(a.D, K).total;
     GSS_TRY(raise_lds_limit(ctx, wcov_kernel<K, true>, lds));
     GSS_PROF(ctx, "em_mstep");
-    hipLaunchKernelGGL((wcov_kernel<K, true>), dim3(a.nch, F), dim3(256), lds, ctx->stream, a.Y,
-                       a.W, a.T, a.D, a.NE, a.nch, a.chunk_frames, a.Bp);
+    hipLaunchKernelGGL((wcov_kernel<K, true>), dim3(xcd_grid(a.nch, F)), dim3(256), lds,
+                       ctx->stream, a.Y, a.W, F, a.T, a.D, a.NE, a.nch, a.chunk_frames, a.Bp);
     GSS_LAUNCH_CHECK(ctx, "wcov_kernel");
     return GSS_OK;
 }
@@ -668,8 +671,8 @@ int psd_partials_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const
                      int nch, int chunk_frames, cplx *part) {
     const size_t lds = wcov_lds_layout(D, 2).total;
     GSS_TRY(raise_lds_limit(ctx, wcov_kernel<2, false>, lds));
-    hipLaunchKernelGGL((wcov_kernel<2, false>), dim3(nch, F), dim3(256), lds, ctx->stream, Y, W2,
-                       T, D, tri_count(D), nch, chunk_frames, part);
+    hipLaunchKernelGGL((wcov_kernel<2, false>), dim3(xcd_grid(nch, F)), dim3(256), lds,
+                       ctx->stream, Y, W2, F, T, D, tri_count(D), nch, chunk_frames, part);
     GSS_LAUNCH_CHECK(ctx, "wcov_kernel");
     return GSS_OK;
 }
@@ -696,6 +699,7 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     a.act = act;
     a.act_stride = act_stride;
     a.T = T;
+    a.F = F;
     a.D = D;
     a.NE = NE;
     a.nch = em_chunks(F, T, &a.chunk_frames);

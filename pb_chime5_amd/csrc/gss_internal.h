@@ -65,6 +65,21 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
+// XCD-aware block mapping for kernels that launch `nsub` workgroups per frequency:
+// the dispatcher is observed to place block b on XCD b % 8 (each XCD has its own
+// L2), so the nsub workgroups of one frequency are given linear ids that are equal
+// mod 8 and share that frequency's slab through one L2.  1-D grid of
+// xcd_grid(nsub, F) blocks; returns false for the padding blocks.  Placement only
+// affects speed, never results.
+__device__ __forceinline__ bool xcd_group_map(int nsub, int F, int &f, int &sub) {
+    const int L = blockIdx.x;
+    const int sg = L / (8 * nsub), rem = L - sg * 8 * nsub;
+    sub = rem >> 3;
+    f = sg * 8 + (rem & 7);
+    return f < F;
+}
+static inline unsigned xcd_grid(int nsub, int F) { return (unsigned)(nsub * ((F + 7) / 8 * 8)); }
+
 // Upper-triangular packed index of (d1 <= d2) in a D x D Hermitian matrix.
 __host__ __device__ __forceinline__ int tri_index(int d1, int d2, int D) {
     return d1 * D - (d1 * (d1 - 1)) / 2 + (d2 - d1);

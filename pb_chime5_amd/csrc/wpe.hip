@@ -55,17 +55,18 @@ struct CorrTile {
 
 // grid: (tile groups, F); block: 256 = 4 waves, one 48 x 48 tile each.
 __global__ __launch_bounds__(256) void wpe_corr_kernel(
-    const cplx *__restrict__ Y, const double *__restrict__ w, int64_t T, int D, int n, int c,
-    int padf, const CorrTile *__restrict__ tiles, int ntiles, cplx *__restrict__ R,
+    const cplx *__restrict__ Y, const double *__restrict__ w, int F, int64_t T, int D, int n,
+    int c, int padf, const CorrTile *__restrict__ tiles, int ntiles, cplx *__restrict__ R,
     cplx *__restrict__ P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int frames_lds = CORR_KT + c + padf;
     cplx *S = reinterpret_cast<cplx *>(smem);                      // frames_lds * D
     double *wS = reinterpret_cast<double *>(S + frames_lds * D);   // CORR_KT
 
-    const int f = blockIdx.y;
+    int f, grp;
+    if (!xcd_group_map((ntiles + 3) / 4, F, f, grp)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile_id = blockIdx.x * 4 + wave;
+    const int tile_id = grp * 4 + wave;
     const bool active = tile_id < ntiles;
     CorrTile tl = tiles[active ? tile_id : 0];
     const int li = lane & 15, lk = lane >> 4;
@@ -449,13 +450,14 @@ constexpr int AP_WAVE_FRAMES = 32;
 constexpr int AP_WG_FRAMES = 4 * AP_WAVE_FRAMES;
 
 __global__ __launch_bounds__(256) void wpe_apply_kernel(const cplx *__restrict__ Y,
-                                                        const cplx *__restrict__ G, int64_t T,
-                                                        int D, int n, int c,
+                                                        const cplx *__restrict__ G, int F,
+                                                        int64_t T, int D, int n, int c,
                                                         cplx *__restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx *S = reinterpret_cast<cplx *>(smem);   // (AP_WG_FRAMES + c + 2) * D
-    const int f = blockIdx.y;
-    const int64_t t0 = (int64_t)blockIdx.x * AP_WG_FRAMES;
+    int f, chunk;
+    if (!xcd_group_map((int)((T + AP_WG_FRAMES - 1) / AP_WG_FRAMES), F, f, chunk)) return;
+    const int64_t t0 = (int64_t)chunk * AP_WG_FRAMES;
     const cplx *Yf = Y + (int64_t)f * T * D;
     const cplx *Gf = G + (int64_t)f * n * D;
     const int frames_lds = AP_WG_FRAMES + c + 2;
@@ -661,8 +663,9 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         }
         {
             GSS_PROF(ctx, "wpe_corr");
-            hipLaunchKernelGGL(wpe_corr_kernel, dim3((ntiles + 3) / 4, F), dim3(256), corr_lds,
-                               ctx->stream, Y, w, T, D, n, c, padf, tiles_dev, ntiles, R, P);
+            hipLaunchKernelGGL(wpe_corr_kernel, dim3(xcd_grid((ntiles + 3) / 4, F)), dim3(256),
+                               corr_lds, ctx->stream, Y, w, F, T, D, n, c, padf, tiles_dev, ntiles,
+                               R, P);
             GSS_LAUNCH_CHECK(ctx, "wpe_corr_kernel");
         }
         const int nblk = (n + CH_NB - 1) / CH_NB;
@@ -698,8 +701,8 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         {
             GSS_PROF(ctx, "wpe_apply");
             hipLaunchKernelGGL(wpe_apply_kernel,
-                               dim3((unsigned)((T + AP_WG_FRAMES - 1) / AP_WG_FRAMES), F),
-                               dim3(256), apply_lds, ctx->stream, Y, P, T, D, n, c, X);
+                               dim3(xcd_grid((int)((T + AP_WG_FRAMES - 1) / AP_WG_FRAMES), F)),
+                               dim3(256), apply_lds, ctx->stream, Y, P, F, T, D, n, c, X);
             GSS_LAUNCH_CHECK(ctx, "wpe_apply_kernel");
         }
     }
