@@ -397,44 +397,122 @@ __global__ __launch_bounds__(256) void chol_update_kernel(cplx *__restrict__ R,
             }
 }
 
-// Blocked back substitution U G = Z, G overwrites Z:  G_J = W_J^H (Z_J - U_J,>J G_>J).
-// The right-hand sides are independent, so each workgroup takes BS_COLS of them:
-// grid (ceil(D / BS_COLS), F), block (BS_COLS * CH_NB) threads = one output each.
-constexpr int BS_COLS = 4;
+// Blocked back substitution U G = Z, G overwrites Z:  G_J = W_J^H (Z_J - U_J,>J G_>J),
+// J descending, both products on the f64 MFMA.  grid (F), block 256: waves 0..2 own
+// one 16-row tile of the 48-row block each (2 column tiles = 32 right-hand sides per
+// pass), so every frequency reads its U exactly once.
+constexpr int BS_LD = 33;   // padded leading dimension of the LDS copy of S
 
-__global__ __launch_bounds__(BS_COLS * CH_NB) void chol_backsolve_kernel(
-    const cplx *__restrict__ R, cplx *__restrict__ P, int n, int D) {
-    __shared__ cplx S[CH_NB * BS_COLS];
-    const int f = blockIdx.y, tid = threadIdx.x;
-    const int dd = tid % BS_COLS, i = tid / BS_COLS;
-    const int d = blockIdx.x * BS_COLS + dd;
-    const bool dv = d < D;
+__global__ __launch_bounds__(256) void chol_backsolve_kernel(const cplx *__restrict__ R,
+                                                             cplx *__restrict__ P, int n, int D) {
+    __shared__ cplx S[CH_NB * BS_LD];
+    const int f = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 15, lk = lane >> 4;
     const cplx *A = R + (int64_t)f * n * n;
     cplx *Z = P + (int64_t)f * n * D;
     const int nblk = (n + CH_NB - 1) / CH_NB;
-    for (int J = nblk - 1; J >= 0; --J) {
-        const int j0 = J * CH_NB, nb = min(CH_NB, n - j0);
-        __syncthreads();
-        // S = Z_J - U_J,>J G_>J
-        cplx v = c_make(0.0, 0.0);
-        if (dv && i < nb) {
-            v = Z[(int64_t)(j0 + i) * D + d];
-            const cplx *urow = A + (int64_t)(j0 + i) * n;
-            for (int k = j0 + nb; k < n; ++k) {
-                const cplx u = urow[k], g = Z[(int64_t)k * D + d];
-                v.x -= u.x * g.x - u.y * g.y;
-                v.y -= u.x * g.y + u.y * g.x;
+    const int a = wave;                       // row tile of this wave (waves 0..2)
+    for (int c0 = 0; c0 < D; c0 += 32) {      // 32 right-hand sides per pass
+        for (int J = nblk - 1; J >= 0; --J) {
+            const int j0 = J * CH_NB, nb = min(CH_NB, n - j0);
+            if (a < 3) {
+                // ---- S = Z_J - U_J,>J G_>J  (rows j0 + 16a .., columns c0 .. c0+31)
+                v4d acc_re[2], acc_im[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int rl = 16 * a + lk + 4 * reg, col = c0 + 16 * b + li;
+                        cplx v = c_make(0.0, 0.0);
+                        if (rl < nb && col < D) v = Z[(int64_t)(j0 + rl) * D + col];
+                        acc_re[b][reg] = v.x;
+                        acc_im[b][reg] = v.y;
+                    }
+                const int kbeg = j0 + nb;
+                const int ksteps = (n - kbeg + 3) / 4;
+                const int arow = 16 * a + li;
+                auto load_ops = [&](int ks, cplx &u, cplx (&g)[2]) {
+                    const int kk = kbeg + 4 * ks + lk;
+                    const bool kv = kk < n;
+                    u = (kv && arow < nb) ? A[(int64_t)(j0 + arow) * n + kk] : c_make(0.0, 0.0);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int col = c0 + 16 * b + li;
+                        g[b] = (kv && col < D) ? Z[(int64_t)kk * D + col] : c_make(0.0, 0.0);
+                    }
+                };
+                cplx u_cur, g_cur[2], u_nxt, g_nxt[2];
+                if (ksteps > 0) load_ops(0, u_cur, g_cur);
+                for (int ks = 0; ks < ksteps; ++ks) {
+                    if (ks + 1 < ksteps) load_ops(ks + 1, u_nxt, g_nxt);
+                    // acc -= u * g
+                    const double nur = -u_cur.x, nui = -u_cur.y, ui = u_cur.y;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        acc_re[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nur, g_cur[b].x, acc_re[b], 0, 0, 0);
+                        acc_im[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nur, g_cur[b].y, acc_im[b], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        acc_re[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui, g_cur[b].y, acc_re[b], 0, 0, 0);
+                        acc_im[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nui, g_cur[b].x, acc_im[b], 0, 0, 0);
+                    }
+                    u_cur = u_nxt;
+                    g_cur[0] = g_nxt[0];
+                    g_cur[1] = g_nxt[1];
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        S[(16 * a + lk + 4 * reg) * BS_LD + 16 * b + li] =
+                            c_make(acc_re[b][reg], acc_im[b][reg]);
             }
-        }
-        S[i * BS_COLS + dd] = v;
-        __syncthreads();
-        // G_J[i] = sum_{k >= i} conj(W[k][i]) S[k],  W[k][k] = 1 / U[k][k]
-        if (dv && i < nb) {
-            const double diag = A[(int64_t)(j0 + i) * n + j0 + i].x;
-            cplx g = c_scale(S[i * BS_COLS + dd], diag > 0.0 ? 1.0 / diag : 0.0);
-            for (int k = i + 1; k < nb; ++k)
-                c_cfma(g, A[(int64_t)(j0 + k) * n + j0 + i], S[k * BS_COLS + dd]);
-            Z[(int64_t)(j0 + i) * D + d] = g;
+            __syncthreads();
+            if (a < 3) {
+                // ---- G_J = W^H S :  out[i][d] = sum_{k >= i} conj(W[k][i]) S[k][d],
+                // W[k][i] (k > i) sits at A[j0+k][j0+i], W[i][i] = 1 / U[i][i]
+                v4d acc_re[2], acc_im[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc_re[b] = (v4d){0.0, 0.0, 0.0, 0.0};
+                    acc_im[b] = (v4d){0.0, 0.0, 0.0, 0.0};
+                }
+                const int i = 16 * a + li;
+                for (int ks = 4 * a; ks < (nb + 3) / 4; ++ks) {
+                    const int k = 4 * ks + lk;
+                    cplx w = c_make(0.0, 0.0);
+                    if (i < nb && k < nb) {
+                        if (k > i) {
+                            w = A[(int64_t)(j0 + k) * n + j0 + i];
+                        } else if (k == i) {
+                            const double d = A[(int64_t)(j0 + i) * n + j0 + i].x;
+                            w = c_make(d > 0.0 ? 1.0 / d : 0.0, 0.0);
+                        }
+                    }
+                    const double nwi = -w.y;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const cplx s = k < nb ? S[k * BS_LD + 16 * b + li] : c_make(0.0, 0.0);
+                        // conj(w) * s
+                        acc_re[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, s.x, acc_re[b], 0, 0, 0);
+                        acc_im[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, s.y, acc_im[b], 0, 0, 0);
+                        acc_re[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.y, s.y, acc_re[b], 0, 0, 0);
+                        acc_im[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nwi, s.x, acc_im[b], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int rl = 16 * a + lk + 4 * reg, col = c0 + 16 * b + li;
+                        if (rl < nb && col < D)
+                            Z[(int64_t)(j0 + rl) * D + col] =
+                                c_make(acc_re[b][reg], acc_im[b][reg]);
+                    }
+            }
+            __syncthreads();
         }
     }
 }
@@ -694,8 +772,8 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         }
         {
             GSS_PROF(ctx, "wpe_backsolve");
-            hipLaunchKernelGGL(chol_backsolve_kernel, dim3((D + BS_COLS - 1) / BS_COLS, F),
-                               dim3(BS_COLS * CH_NB), 0, ctx->stream, R, P, n, D);
+            hipLaunchKernelGGL(chol_backsolve_kernel, dim3(F), dim3(256), 0, ctx->stream, R, P, n,
+                               D);
             GSS_LAUNCH_CHECK(ctx, "chol_backsolve_kernel");
         }
         {
