@@ -14,6 +14,7 @@
 // contraction of the hot path, done here with the f64 MFMA
 // (v_mfma_f64_16x16x4_f64) straight out of an LDS copy of the window.
 #include <algorithm>
+#include <cstdlib>
 
 #include "gss_internal.h"
 
@@ -46,14 +47,15 @@ __global__ __launch_bounds__(256) void wpe_power_kernel(const cplx *__restrict__
 }
 
 // ------------------------------------------------------------------ correlation (MFMA)
-constexpr int CT = 48;        // wave tile edge: 3 x 3 MFMA tiles of 16 x 16
 constexpr int CORR_KT = 64;   // frames staged per chunk
 
 struct CorrTile {
     int row_off, col_off, is_p, pad;
 };
 
-// grid: (tile groups, F); block: 256 = 4 waves, one 48 x 48 tile each.
+// 1-D XCD-mapped grid over (tile groups, F); block: 256 = 4 waves, one
+// (16 TS) x (16 TS) tile each.
+template <int TS, bool M3>
 __global__ __launch_bounds__(256) void wpe_corr_kernel(
     const cplx *__restrict__ Y, const double *__restrict__ w, int F, int64_t T, int D, int n,
     int c, int padf, const CorrTile *__restrict__ tiles, int ntiles, cplx *__restrict__ R,
@@ -73,13 +75,17 @@ __global__ __launch_bounds__(256) void wpe_corr_kernel(
     const cplx *Yf = Y + (int64_t)f * T * D;
     const double *wf = w + (int64_t)f * T;
 
-    v4d acc_re[3][3], acc_im[3][3];
+    // 3M complex product: with t1 = sum ar br, t2 = sum ai bi, t3 = sum (ar+ai)(br-bi)
+    //   re(a conj b) = t1 + t2,   im(a conj b) = t3 - t1 + t2
+    // -- three real MFMAs per tile and k-step instead of four.
+    v4d t1[TS][TS], t2[TS][TS], t3[TS][TS];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < TS; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            acc_re[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-            acc_im[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < TS; ++b) {
+            t1[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+            t2[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+            t3[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
         }
 
     for (int64_t t0 = 0; t0 < T; t0 += CORR_KT) {
@@ -97,36 +103,71 @@ __global__ __launch_bounds__(256) void wpe_corr_kernel(
         __syncthreads();
         if (!active) continue;
         const int ksteps = CORR_KT / 4;
-        for (int ks = 0; ks < ksteps; ++ks) {
-            const int kf = 4 * ks + lk;
-            const double wt = wS[kf];
-            const cplx *base = S + kf * D + li;
-            double ar[3], ai[3], br[3], bi[3], nbi[3];
+        // operands of k-step ks+1 are fetched from LDS while the MFMAs of ks run
+        cplx a_cur[TS], b_cur[TS], a_nxt[TS], b_nxt[TS];
+        double w_cur, w_nxt = 0.0;
+        {
+            const cplx *base = S + lk * D + li;
+            w_cur = wS[lk];
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const cplx a = base[tl.row_off + 16 * m];
-                ar[m] = a.x * wt;
-                ai[m] = a.y * wt;
-                const cplx b = base[tl.col_off + 16 * m];
-                br[m] = b.x;
-                bi[m] = b.y;
-                nbi[m] = -b.y;
+            for (int m = 0; m < TS; ++m) {
+                a_cur[m] = base[tl.row_off + 16 * m];
+                b_cur[m] = base[tl.col_off + 16 * m];
             }
-            // (a_r + i a_i) * (b_r - i b_i)
+        }
+        for (int ks = 0; ks < ksteps; ++ks) {
+            if (ks + 1 < ksteps) {
+                const int kf = 4 * (ks + 1) + lk;
+                const cplx *base = S + kf * D + li;
+                w_nxt = wS[kf];
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], br[b], acc_re[a][b], 0, 0, 0);
-                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], br[b], acc_im[a][b], 0, 0, 0);
+                for (int m = 0; m < TS; ++m) {
+                    a_nxt[m] = base[tl.row_off + 16 * m];
+                    b_nxt[m] = base[tl.col_off + 16 * m];
                 }
+            }
+            double ar[TS], ai[TS], as[TS], br[TS], bi[TS], bd[TS];
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
+            for (int m = 0; m < TS; ++m) {
+                ar[m] = a_cur[m].x * w_cur;
+                ai[m] = a_cur[m].y * w_cur;
+                as[m] = ar[m] + ai[m];
+                br[m] = b_cur[m].x;
+                bi[m] = b_cur[m].y;
+                bd[m] = b_cur[m].x - b_cur[m].y;
+            }
+            if (M3) {
 #pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], bi[b], acc_re[a][b], 0, 0, 0);
-                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], nbi[b], acc_im[a][b], 0, 0, 0);
-                }
+                for (int a = 0; a < TS; ++a)
+#pragma unroll
+                    for (int b = 0; b < TS; ++b) {
+                        t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], br[b], t1[a][b], 0, 0, 0);
+                        t2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], bi[b], t2[a][b], 0, 0, 0);
+                        t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[a], bd[b], t3[a][b], 0, 0, 0);
+                    }
+            } else {
+                // 4M: t1 = re, t3 = im  (t2 unused)
+#pragma unroll
+                for (int a = 0; a < TS; ++a)
+#pragma unroll
+                    for (int b = 0; b < TS; ++b) {
+                        t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], br[b], t1[a][b], 0, 0, 0);
+                        t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], br[b], t3[a][b], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int a = 0; a < TS; ++a)
+#pragma unroll
+                    for (int b = 0; b < TS; ++b) {
+                        t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], bi[b], t1[a][b], 0, 0, 0);
+                        t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], -bi[b], t3[a][b], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int m = 0; m < TS; ++m) {
+                a_cur[m] = a_nxt[m];
+                b_cur[m] = b_nxt[m];
+            }
+            w_cur = w_nxt;
         }
     }
     if (!active) return;
@@ -134,14 +175,16 @@ __global__ __launch_bounds__(256) void wpe_corr_kernel(
     cplx *Rf = R + (int64_t)f * n * n;
     cplx *Pf = P + (int64_t)f * n * D;
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < TS; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
+        for (int b = 0; b < TS; ++b)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = tl.row_off + 16 * a + lk + 4 * reg;
                 const int cc = tl.col_off + 16 * b + li;
-                const cplx v = c_make(acc_re[a][b][reg], acc_im[a][b][reg]);
+                const cplx v = M3 ? c_make(t1[a][b][reg] + t2[a][b][reg],
+                                           (t3[a][b][reg] - t1[a][b][reg]) + t2[a][b][reg])
+                                  : c_make(t1[a][b][reg], t3[a][b][reg]);
                 if (r >= n) continue;
                 if (tl.is_p) {
                     const int d = cc - c * D;
@@ -298,7 +341,8 @@ struct UpdTile {
     int row_off, col_off, is_p, pad;
 };
 
-// grid (tile groups, F), block 256 = 4 waves, one 48 x 48 tile each.
+// grid (tile groups, F), block 256 = 4 waves, one (16 TM) x (16 TN) tile each.
+template <int TM, int TN, bool PREFETCH>
 __global__ __launch_bounds__(256) void chol_update_kernel(cplx *__restrict__ R,
                                                           cplx *__restrict__ P, int n, int D,
                                                           int j0, int nb,
@@ -316,13 +360,16 @@ __global__ __launch_bounds__(256) void chol_update_kernel(cplx *__restrict__ R,
     const cplx *zpanel = Z + (int64_t)j0 * D;
     const int ncols = tl.is_p ? D : n;
 
-    auto load_ops = [&](int ks, cplx (&a)[3], cplx (&b)[3]) {
+    auto load_ops = [&](int ks, cplx (&a)[TM], cplx (&b)[TN]) {
         const int kk = 4 * ks + lk;
         const bool kv = kk < nb;
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
+        for (int m = 0; m < TM; ++m) {
             const int ri = tl.row_off + 16 * m + li;
             a[m] = (kv && ri < n) ? panel[(int64_t)kk * n + ri] : c_make(0.0, 0.0);
+        }
+#pragma unroll
+        for (int m = 0; m < TN; ++m) {
             const int ci = tl.col_off + 16 * m + li;
             b[m] = c_make(0.0, 0.0);
             if (kv && ci < ncols)
@@ -331,15 +378,15 @@ __global__ __launch_bounds__(256) void chol_update_kernel(cplx *__restrict__ R,
     };
 
     const int ksteps = (nb + 3) / 4;
-    cplx a_cur[3], b_cur[3], a_nxt[3], b_nxt[3];
+    cplx a_cur[TM], b_cur[TN], a_nxt[TM], b_nxt[TN];
     load_ops(0, a_cur, b_cur);
 
-    v4d acc_re[3][3], acc_im[3][3];
+    v4d acc_re[TM][TN], acc_im[TM][TN];
     // load C in fragment layout: col = li, row = lk + 4 * reg
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = tl.row_off + 16 * a + lk + 4 * reg;
@@ -350,41 +397,49 @@ __global__ __launch_bounds__(256) void chol_update_kernel(cplx *__restrict__ R,
                 acc_im[a][b][reg] = v.y;
             }
     for (int ks = 0; ks < ksteps; ++ks) {
-        if (ks + 1 < ksteps) load_ops(ks + 1, a_nxt, b_nxt);
-        double nar[3], nai[3], ai[3], br[3], bi[3];
+        if (PREFETCH) {
+            if (ks + 1 < ksteps) load_ops(ks + 1, a_nxt, b_nxt);
+        } else if (ks > 0) {
+            load_ops(ks, a_cur, b_cur);
+        }
+        double nar[TM], nai[TM], ai[TM], br[TN], bi[TN];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
+        for (int m = 0; m < TM; ++m) {
             nar[m] = -a_cur[m].x;
             nai[m] = -a_cur[m].y;
             ai[m] = a_cur[m].y;
+        }
+#pragma unroll
+        for (int m = 0; m < TN; ++m) {
             br[m] = b_cur[m].x;
             bi[m] = b_cur[m].y;
         }
         // C -= conj(a) b :  re -= ar br + ai bi ;  im -= ar bi - ai br
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
+            for (int b = 0; b < TN; ++b) {
                 acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nar[a], br[b], acc_re[a][b], 0, 0, 0);
                 acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nar[a], bi[b], acc_im[a][b], 0, 0, 0);
             }
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
+            for (int b = 0; b < TN; ++b) {
                 acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai[a], bi[b], acc_re[a][b], 0, 0, 0);
                 acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], br[b], acc_im[a][b], 0, 0, 0);
             }
+        if (PREFETCH) {
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            a_cur[m] = a_nxt[m];
-            b_cur[m] = b_nxt[m];
+            for (int m = 0; m < TM; ++m) a_cur[m] = a_nxt[m];
+#pragma unroll
+            for (int m = 0; m < TN; ++m) b_cur[m] = b_nxt[m];
         }
     }
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = tl.row_off + 16 * a + lk + 4 * reg;
@@ -642,17 +697,17 @@ __global__ void mfma_selftest_kernel(double *out) {
 
 }  // namespace
 
-static int corr_tiles(int n, int D, int c, std::vector<CorrTile> &tiles) {
-    const int nt = (n + CT - 1) / CT;
-    for (int i = 0; i < nt; ++i)
-        for (int j = i; j < nt; ++j) tiles.push_back({i * CT, j * CT, 0, 0});
-    const int np = (D + CT - 1) / CT;
-    for (int i = 0; i < nt; ++i)
-        for (int j = 0; j < np; ++j) tiles.push_back({i * CT, c * D + j * CT, 1, 0});
+static int corr_tiles(int n, int D, int c, int ct, std::vector<CorrTile> &tiles) {
+    // R: every ct x ct tile that reaches the upper triangle; P: all rows x D columns
+    for (int r0 = 0; r0 < n; r0 += ct)
+        for (int c0 = 0; c0 < n; c0 += ct)
+            if (c0 + ct > r0) tiles.push_back({r0, c0, 0, 0});
+    for (int r0 = 0; r0 < n; r0 += ct)
+        for (int c0 = 0; c0 < D; c0 += ct) tiles.push_back({r0, c * D + c0, 1, 0});
     return (int)tiles.size();
 }
 
-static int corr_padf(int D) { return (CT + D - 1) / D + 1; }
+static int corr_padf(int D, int ct) { return (ct + D - 1) / D + 1; }
 
 size_t wpe_workspace_bytes(int F, int64_t T, int D, int taps, int delay) {
     const size_t n = (size_t)taps * D;
@@ -681,16 +736,26 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
 
     // tile lists: correlation tiles, then one trailing-update list per block column
     std::vector<CorrTile> tiles;
-    const int ntiles = corr_tiles(n, D, c, tiles);
+    int corr_ts = 2;
+    if (const char *e = getenv("GSS_CORR_TS")) corr_ts = atoi(e) == 3 ? 3 : 2;
+    const int ntiles = corr_tiles(n, D, c, 16 * corr_ts, tiles);
+    // trailing-update tiles: (16 TM) x (16 TN), every tile that reaches the upper triangle
+    int upd_variant = 0;
+    if (const char *e = getenv("GSS_UPD_VARIANT")) upd_variant = atoi(e);
+    else upd_variant = 6;
+    static const int UPD_TM[] = {3, 3, 2, 2, 2, 1, 1, 2}, UPD_TN[] = {3, 3, 3, 2, 2, 2, 1, 4};
+    const int tm16 = 16 * UPD_TM[upd_variant & 7], tn16 = 16 * UPD_TN[upd_variant & 7];
     std::vector<UpdTile> upd;
     std::vector<int> upd_start, upd_count;
     {
         const int nblk = (n + CH_NB - 1) / CH_NB;
         for (int J = 0; J < nblk; ++J) {
             upd_start.push_back((int)upd.size());
-            for (int I = J + 1; I < nblk; ++I) {
-                for (int Kb = I; Kb < nblk; ++Kb) upd.push_back({I * CH_NB, Kb * CH_NB, 0, 0});
-                for (int cc = 0; cc < D; cc += CH_NB) upd.push_back({I * CH_NB, cc, 1, 0});
+            const int rs = (J + 1) * CH_NB;
+            for (int r0 = rs; r0 < n; r0 += tm16) {
+                for (int c0 = rs; c0 < n; c0 += tn16)
+                    if (c0 + tn16 > r0) upd.push_back({r0, c0, 0, 0});
+                for (int cc = 0; cc < D; cc += tn16) upd.push_back({r0, cc, 1, 0});
             }
             upd_count.push_back((int)upd.size() - upd_start.back());
         }
@@ -699,7 +764,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                 "wpe: taps*D=%d too large", n);
     static_assert(sizeof(CorrTile) == sizeof(UpdTile), "tile structs share one buffer");
     if (ctx->wpe_tiles_key[0] != taps || ctx->wpe_tiles_key[1] != delay ||
-        ctx->wpe_tiles_key[2] != D) {
+        ctx->wpe_tiles_key[2] != D + 1000 * upd_variant + 100000 * corr_ts) {
         GSS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (!ctx->wpe_tiles)
             GSS_HIP_CHECK(ctx, hipMalloc(&ctx->wpe_tiles, sizeof(CorrTile) * (1024 + 4096)));
@@ -711,12 +776,15 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                                          hipMemcpyHostToDevice));
         ctx->wpe_tiles_key[0] = taps;
         ctx->wpe_tiles_key[1] = delay;
-        ctx->wpe_tiles_key[2] = D;
+        ctx->wpe_tiles_key[2] = D + 1000 * upd_variant + 100000 * corr_ts;
     }
     CorrTile *tiles_dev = reinterpret_cast<CorrTile *>(ctx->wpe_tiles);
     UpdTile *upd_dev = reinterpret_cast<UpdTile *>(tiles_dev + 1024);
 
-    const int padf = corr_padf(D);
+    const int padf = corr_padf(D, 16 * corr_ts);
+    const bool corr_3m = getenv("GSS_CORR_3M") != nullptr;
+    auto corr_fn = corr_ts == 2 ? (corr_3m ? wpe_corr_kernel<2, true> : wpe_corr_kernel<2, false>)
+                                : (corr_3m ? wpe_corr_kernel<3, true> : wpe_corr_kernel<3, false>);
     const size_t corr_lds = sizeof(cplx) * (size_t)(CORR_KT + c + padf) * D + sizeof(double) * CORR_KT;
     const size_t panel_lds = sizeof(cplx) * CH_NB * CH_NB + sizeof(double) * CH_NB;
     const size_t trsm_lds = sizeof(cplx) * (CH_NB * CH_NB + CH_NB * TRSM_COLS);
@@ -728,7 +796,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)apply_lds));
     if (corr_lds > 64 * 1024)
-        GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(wpe_corr_kernel),
+        GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(corr_fn),
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)corr_lds));
 
@@ -741,9 +809,8 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         }
         {
             GSS_PROF(ctx, "wpe_corr");
-            hipLaunchKernelGGL(wpe_corr_kernel, dim3(xcd_grid((ntiles + 3) / 4, F)), dim3(256),
-                               corr_lds, ctx->stream, Y, w, F, T, D, n, c, padf, tiles_dev, ntiles,
-                               R, P);
+            hipLaunchKernelGGL(corr_fn, dim3(xcd_grid((ntiles + 3) / 4, F)), dim3(256), corr_lds,
+                               ctx->stream, Y, w, F, T, D, n, c, padf, tiles_dev, ntiles, R, P);
             GSS_LAUNCH_CHECK(ctx, "wpe_corr_kernel");
         }
         const int nblk = (n + CH_NB - 1) / CH_NB;
@@ -765,8 +832,42 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
             const int nupd = upd_count[J];
             if (nupd > 0) {
                 GSS_PROF(ctx, "wpe_chol_update");
-                hipLaunchKernelGGL(chol_update_kernel, dim3((nupd + 3) / 4, F), dim3(256), 0,
-                                   ctx->stream, R, P, n, D, j0, nb, upd_dev + upd_start[J], nupd);
+                const dim3 g((nupd + 3) / 4, F), b(256);
+                const UpdTile *tl = upd_dev + upd_start[J];
+                switch (upd_variant & 7) {
+                    case 0:
+                        hipLaunchKernelGGL((chol_update_kernel<3, 3, true>), g, b, 0, ctx->stream,
+                                           R, P, n, D, j0, nb, tl, nupd);
+                        break;
+                    case 1:
+                        hipLaunchKernelGGL((chol_update_kernel<3, 3, false>), g, b, 0, ctx->stream,
+                                           R, P, n, D, j0, nb, tl, nupd);
+                        break;
+                    case 2:
+                        hipLaunchKernelGGL((chol_update_kernel<2, 3, true>), g, b, 0, ctx->stream,
+                                           R, P, n, D, j0, nb, tl, nupd);
+                        break;
+                    case 3:
+                        hipLaunchKernelGGL((chol_update_kernel<2, 2, true>), g, b, 0, ctx->stream,
+                                           R, P, n, D, j0, nb, tl, nupd);
+                        break;
+                    case 4:
+                        hipLaunchKernelGGL((chol_update_kernel<2, 2, false>), g, b, 0, ctx->stream,
+                                           R, P, n, D, j0, nb, tl, nupd);
+                        break;
+                    case 5:
+                        hipLaunchKernelGGL((chol_update_kernel<1, 2, true>), g, b, 0, ctx->stream,
+                                           R, P, n, D, j0, nb, tl, nupd);
+                        break;
+                    case 6:
+                        hipLaunchKernelGGL((chol_update_kernel<1, 1, true>), g, b, 0, ctx->stream,
+                                           R, P, n, D, j0, nb, tl, nupd);
+                        break;
+                    default:
+                        hipLaunchKernelGGL((chol_update_kernel<2, 4, true>), g, b, 0, ctx->stream,
+                                           R, P, n, D, j0, nb, tl, nupd);
+                        break;
+                }
                 GSS_LAUNCH_CHECK(ctx, "chol_update_kernel");
             }
         }
