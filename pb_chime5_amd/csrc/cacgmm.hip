@@ -231,6 +231,113 @@ __global__ __launch_bounds__(256) void em_estep_kernel(EmArgs a, const cplx *__r
     }
 }
 
+// ------------------------------------------------------------------ E-step, register form
+// For the channel counts that matter (D = 24: 6 arrays x 4, D = 12: outer mics of 6
+// arrays) the E-step runs without LDS and without any barrier: the unit-normalised
+// observation is kept once per utterance in (F, D, T) layout (em_prepare), a lane owns
+// one frame, pulls its D channel values with coalesced loads into registers, walks the
+// packed upper triangle fully unrolled with the model row in SGPRs (scalar loads), and
+// finishes the softmax in registers.  Lanes never exchange data.
+__global__ __launch_bounds__(256) void em_prepare_kernel(const cplx *__restrict__ Y, int F,
+                                                         int64_t T, int D,
+                                                         cplx *__restrict__ Yn) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx *ys = reinterpret_cast<cplx *>(smem);                  // D * EM_TS
+    double *scratch = reinterpret_cast<double *>(ys + D * EM_TS);
+    int f, tile;
+    if (!xcd_group_map((int)((T + EM_TILE - 1) / EM_TILE), F, f, tile)) return;
+    const int tid = threadIdx.x, tl = tid & 63, g = tid >> 6;
+    const int64_t t0 = (int64_t)tile * EM_TILE;
+    load_tile<true>(Y + (int64_t)f * T * D, D, t0, T, tl, g, ys, scratch);
+    __syncthreads();
+    const int64_t t = t0 + tl;
+    if (t < T)
+        for (int d = g; d < D; d += 4) Yn[((int64_t)f * D + d) * T + t] = ys[d * EM_TS + tl];
+}
+
+template <int K, int D, int MODE>
+__global__ __launch_bounds__(256) void em_estep_reg_kernel(EmArgs a, const cplx *__restrict__ Mq,
+                                                           const cplx *__restrict__ Yn) {
+    constexpr int NE = D * (D + 1) / 2;
+    const int64_t T = a.T;
+    const int ntile = (int)((T + 255) / 256);
+    int f, tile;
+    if (!xcd_group_map(ntile, a.F, f, tile)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t t = (int64_t)tile * 256 + wave * 64 + lane;
+    const bool valid = t < T;
+    const int64_t tc = valid ? t : T - 1;
+    const cplx *Mf = Mq + (int64_t)f * NE * K;
+    const cplx *yf = Yn + (int64_t)f * D * T + tc;
+
+    cplx y[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) y[d] = yf[(int64_t)d * T];
+
+    double q[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = 0.0;
+    // Walk the packed upper triangle with a ring of model rows: the row of entry e + P
+    // is requested (scalar loads, wave uniform) before entry e is evaluated, and a
+    // scheduling barrier per entry keeps the compiler from hoisting every row of the
+    // fully unrolled triangle to the top (which would spill thousands of SGPRs).
+    constexpr int P = 2, RING = P + 1;
+    cplx ring[RING][K];
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int k = 0; k < K; ++k) ring[j][k] = Mf[j * K + k];
+    int e = 0;
+#pragma unroll
+    for (int d1 = 0; d1 < D; ++d1) {
+#pragma unroll
+        for (int d2 = d1; d2 < D; ++d2) {
+            if (e + P < NE) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) ring[(e + P) % RING][k] = Mf[(e + P) * K + k];
+            }
+            const double pr = y[d1].x * y[d2].x + y[d1].y * y[d2].y;
+            const double pim = y[d1].y * y[d2].x - y[d1].x * y[d2].y;   // 0 on the diagonal
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const cplx m = ring[e % RING][k];
+                q[k] = fma(m.x, pr, q[k]);
+                q[k] = fma(m.y, pim, q[k]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ++e;
+        }
+    }
+    double lp[K], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        q[k] = fmax(fabs(q[k]), GSS_TINY);
+        lp[k] = -(double)D * log(q[k]) - a.logdet[f * K + k];
+        mx = fmax(mx, lp[k]);
+    }
+    double v[K], ssum = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        v[k] = exp(lp[k] - mx) * a.pi[f * K + k];
+        if (a.masked) v[k] *= (valid && a.act[(int64_t)k * a.act_stride + tc]) ? 1.0 : 0.0;
+        ssum += v[k];
+    }
+    ssum = fmax(ssum, GSS_TINY);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double gam = v[k] / ssum;
+        if (a.aff_eps != 0.0) gam = fmin(fmax(gam, a.aff_eps), 1.0 - a.aff_eps);
+        if (MODE == MODE_PREDICT) {
+            if (valid) a.gamma[((int64_t)f * K + k) * T + t] = gam;
+        } else {
+            if (valid) a.W[((int64_t)f * K + k) * T + t] = gam / fmax(q[k], 10.0 * GSS_TINY);
+            const double tot = wave_sum(valid ? gam : 0.0);
+            if (lane == 0) a.Sg[(((int64_t)f * ntile + tile) * 4 + wave) * K + k] = tot;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ M-step
 // Partial sums over a chunk of frames of  w_k(t) y y^H  for KW weight rows, upper
 // triangle in 2 x 2 register blocks; thread = (block, frame group).  Shared by the
@@ -469,7 +576,8 @@ __device__ inline double load_covariance(const cplx *__restrict__ Bp, int nch, i
 // B^-1 and ln det B from a Cholesky factorisation give the same posteriors.
 // Matrices that fail the certificate are flagged for em_eigh_kernel.
 __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp,
-                                                     const double *__restrict__ Sg, int nch, int D,
+                                                     const double *__restrict__ Sg, int nch,
+                                                     int sg_nch, int D,
                                                      int K, int64_t T, double eig_floor,
                                                      int force_eigh, cplx *__restrict__ Mq,
                                                      double *__restrict__ logdet,
@@ -482,7 +590,7 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
     const int k = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
 
     double sg = 0.0;
-    for (int c = 0; c < nch; ++c) sg += Sg[((int64_t)f * nch + c) * K + k];
+    for (int c = 0; c < sg_nch; ++c) sg += Sg[((int64_t)f * sg_nch + c) * K + k];
     const double den = fmax(sg, GSS_TINY);
     if (lane == 0) pi[f * K + k] = sg / (double)T;
 
@@ -528,7 +636,8 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
 // Eigendecomposition path for the flagged matrices: eigenvalues / max, floor, then
 // B^-1 = V diag(1/lambda) V^H and ln det = sum ln lambda, exactly as the reference.
 __global__ __launch_bounds__(64) void em_eigh_kernel(const cplx *__restrict__ Bp,
-                                                     const double *__restrict__ Sg, int nch, int D,
+                                                     const double *__restrict__ Sg, int nch,
+                                                     int sg_nch, int D,
                                                      int K, double eig_floor,
                                                      const int *__restrict__ need_eigh,
                                                      cplx *__restrict__ Mq,
@@ -543,7 +652,7 @@ __global__ __launch_bounds__(64) void em_eigh_kernel(const cplx *__restrict__ Bp
     double *lam = reinterpret_cast<double *>(V + m * m);   // m
 
     double sg = 0.0;
-    for (int c = 0; c < nch; ++c) sg += Sg[((int64_t)f * nch + c) * K + k];
+    for (int c = 0; c < sg_nch; ++c) sg += Sg[((int64_t)f * sg_nch + c) * K + k];
     const double den = fmax(sg, GSS_TINY);
     for (int idx = lane; idx < m * m; idx += 64) A[idx] = c_make(0.0, 0.0);
     __syncthreads();
@@ -630,6 +739,39 @@ int launch_estep(gss_ctx *ctx, int mode, const EmArgs &a, const cplx *Mq, int F)
     return GSS_OK;
 }
 
+template <int K, int D>
+int launch_estep_reg(gss_ctx *ctx, int mode, const EmArgs &a, const cplx *Mq, const cplx *Yn,
+                     int F) {
+    const dim3 grid(xcd_grid((int)((a.T + 255) / 256), F)), block(256);
+    if (mode == MODE_EM) {
+        GSS_PROF(ctx, "em_estep");
+        hipLaunchKernelGGL((em_estep_reg_kernel<K, D, MODE_EM>), grid, block, 0, ctx->stream, a,
+                           Mq, Yn);
+    } else {
+        GSS_PROF(ctx, "em_predict");
+        hipLaunchKernelGGL((em_estep_reg_kernel<K, D, MODE_PREDICT>), grid, block, 0, ctx->stream,
+                           a, Mq, Yn);
+    }
+    GSS_LAUNCH_CHECK(ctx, "em_estep_reg_kernel");
+    return GSS_OK;
+}
+
+// Channel / class counts with a register-form E-step.
+bool estep_reg_supported(int D, int K) { return (D == 24 || D == 12) && K >= 2 && K <= 6; }
+
+template <int D>
+int launch_estep_reg_k(gss_ctx *ctx, int K, int mode, const EmArgs &a, const cplx *Mq,
+                       const cplx *Yn, int F) {
+    switch (K) {
+        case 2: return launch_estep_reg<2, D>(ctx, mode, a, Mq, Yn, F);
+        case 3: return launch_estep_reg<3, D>(ctx, mode, a, Mq, Yn, F);
+        case 4: return launch_estep_reg<4, D>(ctx, mode, a, Mq, Yn, F);
+        case 5: return launch_estep_reg<5, D>(ctx, mode, a, Mq, Yn, F);
+        case 6: return launch_estep_reg<6, D>(ctx, mode, a, Mq, Yn, F);
+    }
+    return gss_fail(ctx, GSS_ERR_UNSUPPORTED, "cacgmm: K=%d", K);
+}
+
 template <int K>
 int launch_mstep(gss_ctx *ctx, const EmArgs &a, int F) {
     const size_t lds = wcov_lds_layout(a.D, K).total;
@@ -688,6 +830,8 @@ size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K) {
     b += align_up(sizeof(cplx) * (size_t)F * nch * K * NE);      // Bp
     b += align_up(sizeof(double) * (size_t)F * nch * K);         // Sg
     b += align_up(sizeof(int) * (size_t)F * K);                  // need_eigh
+    b += align_up(sizeof(cplx) * (size_t)F * D * T);             // Yn (register-form E-step)
+    b += align_up(sizeof(double) * (size_t)F * 4 * ((T + 255) / 256) * K);
     return b + 4096;
 }
 
@@ -714,6 +858,33 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     a.logdet = logdet;
     a.pi = pi;
     a.gamma = gamma;
+    // register-form E-step: normalised observation in (F, D, T) layout, its own
+    // (finer) partial sums of gamma
+    const bool reg = estep_reg_supported(D, K) && getenv("GSS_ESTEP_LDS") == nullptr;
+    const int reg_nch = 4 * (int)((T + 255) / 256);
+    cplx *Yn = nullptr;
+    double *Sg_lds = a.Sg, *Sg_reg = nullptr;
+    const int nch_lds = a.nch;
+    if (reg) {
+        Yn = arena_alloc_t<cplx>(ctx, (size_t)F * D * T);
+        Sg_reg = arena_alloc_t<double>(ctx, (size_t)F * reg_nch * K);
+        GSS_REQUIRE(ctx, Yn && Sg_reg, GSS_ERR_NOMEM, "cacgmm workspace");
+        GSS_PROF(ctx, "em_prepare");
+        const size_t plds = sizeof(cplx) * (size_t)D * EM_TS + sizeof(double) * 4 * EM_TILE;
+        hipLaunchKernelGGL(em_prepare_kernel,
+                           dim3(xcd_grid((int)((T + EM_TILE - 1) / EM_TILE), F)), dim3(256), plds,
+                           ctx->stream, Y, F, T, D, Yn);
+        GSS_LAUNCH_CHECK(ctx, "em_prepare_kernel");
+    }
+    auto estep = [&](int mode) -> int {
+        if (reg && mode != MODE_FIRST) {
+            a.Sg = Sg_reg;
+            if (D == 24) return launch_estep_reg_k<24>(ctx, K, mode, a, Mq, Yn, F);
+            return launch_estep_reg_k<12>(ctx, K, mode, a, Mq, Yn, F);
+        }
+        a.Sg = Sg_lds;
+        return launch_estep_k(ctx, K, mode, a, Mq, F);
+    };
 
     GSS_REQUIRE(ctx, em_estep_lds(D, K) <= 160 * 1024 && wcov_lds_layout(D, K).total <= 160 * 1024,
                 GSS_ERR_UNSUPPORTED, "cacgmm: D=%d K=%d LDS", D, K);
@@ -724,17 +895,19 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     int *need_eigh = arena_alloc_t<int>(ctx, (size_t)F * K);
     GSS_REQUIRE(ctx, need_eigh, GSS_ERR_NOMEM, "cacgmm workspace");
 
+    int sg_nch = nch_lds;
     auto eig = [&]() -> int {
         {
             GSS_PROF(ctx, "em_chol");
             hipLaunchKernelGGL(em_chol_kernel, dim3(K, F), dim3(64), chol_lds, ctx->stream, a.Bp,
-                               a.Sg, a.nch, D, K, T, 1e-10, force_eigh, Mq, logdet, pi, need_eigh);
+                               a.Sg, a.nch, sg_nch, D, K, T, 1e-10, force_eigh, Mq, logdet, pi,
+                               need_eigh);
             GSS_LAUNCH_CHECK(ctx, "em_chol_kernel");
         }
         {
             GSS_PROF(ctx, "em_eigh");
             hipLaunchKernelGGL(em_eigh_kernel, dim3(K, F), dim3(64), eigh_lds, ctx->stream, a.Bp,
-                               a.Sg, a.nch, D, K, 1e-10, need_eigh, Mq, logdet);
+                               a.Sg, a.nch, sg_nch, D, K, 1e-10, need_eigh, Mq, logdet);
             GSS_LAUNCH_CHECK(ctx, "em_eigh_kernel");
         }
         return GSS_OK;
@@ -744,7 +917,8 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     for (int it = 0; it < iterations; ++it) {
         a.masked = 1;
         a.aff_eps = 1e-10;
-        GSS_TRY(launch_estep_k(ctx, K, it == 0 ? MODE_FIRST : MODE_EM, a, Mq, F));
+        GSS_TRY(estep(it == 0 ? MODE_FIRST : MODE_EM));
+        sg_nch = (reg && it != 0) ? reg_nch : nch_lds;
         GSS_TRY(launch_mstep_k(ctx, K, a, F));
         GSS_TRY(eig());
     }
@@ -753,7 +927,8 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
         for (int it = 0; it < iterations_post - 1; ++it) {
             a.masked = 0;
             a.aff_eps = 1e-10;
-            GSS_TRY(launch_estep_k(ctx, K, MODE_EM, a, Mq, F));
+            GSS_TRY(estep(MODE_EM));
+            sg_nch = reg ? reg_nch : nch_lds;
             GSS_TRY(launch_mstep_k(ctx, K, a, F));
             GSS_TRY(eig());
         }
@@ -761,6 +936,6 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     // predict: affiliation_eps = 0; mask only when iterations_post == 0
     a.masked = iterations_post == 0 ? 1 : 0;
     a.aff_eps = 0.0;
-    GSS_TRY(launch_estep_k(ctx, K, MODE_PREDICT, a, Mq, F));
+    GSS_TRY(estep(MODE_PREDICT));
     return GSS_OK;
 }
