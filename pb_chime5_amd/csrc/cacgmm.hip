@@ -369,7 +369,7 @@ __host__ __device__ inline WcovLds wcov_lds_layout(int D, int KW) {
     return L;
 }
 
-template <int KW, bool NORMALISE>
+template <int KW, bool NORMALISE, bool SRC_FDT>
 __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
                                                    const double *__restrict__ W, int F,
                                                    int64_t T, int D, int NE, int nch,
@@ -414,7 +414,14 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
 
     for (int64_t t0 = c0; t0 < c1; t0 += EM_TILE) {
         __syncthreads();
-        load_tile<NORMALISE>(Yf, D, t0, c1, tl, g, ys, scratch);
+        if (SRC_FDT) {
+            // Y is already the (F, D, T) unit-normalised copy: rows are contiguous
+            const cplx *src = Y + (int64_t)f * D * T;
+            for (int d = g; d < D; d += 4)
+                ys[d * EM_TS + tl] = t0 + tl < c1 ? src[(int64_t)d * T + t0 + tl] : c_make(0.0, 0.0);
+        } else {
+            load_tile<NORMALISE>(Yf, D, t0, c1, tl, g, ys, scratch);
+        }
         for (int idx = tid; idx < KW * EM_TILE; idx += blockDim.x) {
             const int k = idx / EM_TILE, j = idx - k * EM_TILE;
             wk[idx] = t0 + j < c1 ? Wf[(int64_t)k * T + t0 + j] : 0.0;
@@ -773,11 +780,18 @@ int launch_estep_reg_k(gss_ctx *ctx, int K, int mode, const EmArgs &a, const cpl
 }
 
 template <int K>
-int launch_mstep(gss_ctx *ctx, const EmArgs &a, int F) {
+int launch_mstep(gss_ctx *ctx, const EmArgs &a, const cplx *Yn, int F) {
     const size_t lds = wcov_lds_layout(a.D, K).total;
-    GSS_TRY(raise_lds_limit(ctx, wcov_kernel<K, true>, lds));
     GSS_PROF(ctx, "em_mstep");
-    hipLaunchKernelGGL((wcov_kernel<K, true>), dim3(xcd_grid(a.nch, F)), dim3(256), lds,
+    if (Yn) {
+        GSS_TRY(raise_lds_limit(ctx, wcov_kernel<K, false, true>, lds));
+        hipLaunchKernelGGL((wcov_kernel<K, false, true>), dim3(xcd_grid(a.nch, F)), dim3(256), lds,
+                           ctx->stream, Yn, a.W, F, a.T, a.D, a.NE, a.nch, a.chunk_frames, a.Bp);
+        GSS_LAUNCH_CHECK(ctx, "wcov_kernel");
+        return GSS_OK;
+    }
+    GSS_TRY(raise_lds_limit(ctx, wcov_kernel<K, true, false>, lds));
+    hipLaunchKernelGGL((wcov_kernel<K, true, false>), dim3(xcd_grid(a.nch, F)), dim3(256), lds,
                        ctx->stream, a.Y, a.W, F, a.T, a.D, a.NE, a.nch, a.chunk_frames, a.Bp);
     GSS_LAUNCH_CHECK(ctx, "wcov_kernel");
     return GSS_OK;
@@ -800,8 +814,8 @@ int launch_estep_k(gss_ctx *ctx, int K, int mode, const EmArgs &a, const cplx *M
     return gss_fail(ctx, GSS_ERR_UNSUPPORTED, "cacgmm: K=%d", K);
 }
 
-int launch_mstep_k(gss_ctx *ctx, int K, const EmArgs &a, int F) {
-    GSS_K_SWITCH(K, launch_mstep<KK>(ctx, a, F));
+int launch_mstep_k(gss_ctx *ctx, int K, const EmArgs &a, const cplx *Yn, int F) {
+    GSS_K_SWITCH(K, launch_mstep<KK>(ctx, a, Yn, F));
     return gss_fail(ctx, GSS_ERR_UNSUPPORTED, "cacgmm: K=%d", K);
 }
 
@@ -812,8 +826,8 @@ int launch_mstep_k(gss_ctx *ctx, int K, const EmArgs &a, int F) {
 int psd_partials_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double *W2,
                      int nch, int chunk_frames, cplx *part) {
     const size_t lds = wcov_lds_layout(D, 2).total;
-    GSS_TRY(raise_lds_limit(ctx, wcov_kernel<2, false>, lds));
-    hipLaunchKernelGGL((wcov_kernel<2, false>), dim3(xcd_grid(nch, F)), dim3(256), lds,
+    GSS_TRY(raise_lds_limit(ctx, wcov_kernel<2, false, false>, lds));
+    hipLaunchKernelGGL((wcov_kernel<2, false, false>), dim3(xcd_grid(nch, F)), dim3(256), lds,
                        ctx->stream, Y, W2, F, T, D, tri_count(D), nch, chunk_frames, part);
     GSS_LAUNCH_CHECK(ctx, "wcov_kernel");
     return GSS_OK;
@@ -919,7 +933,7 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
         a.aff_eps = 1e-10;
         GSS_TRY(estep(it == 0 ? MODE_FIRST : MODE_EM));
         sg_nch = (reg && it != 0) ? reg_nch : nch_lds;
-        GSS_TRY(launch_mstep_k(ctx, K, a, F));
+        GSS_TRY(launch_mstep_k(ctx, K, a, Yn, F));
         GSS_TRY(eig());
     }
     if (iterations_post > 1) {
@@ -929,7 +943,7 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
             a.aff_eps = 1e-10;
             GSS_TRY(estep(MODE_EM));
             sg_nch = reg ? reg_nch : nch_lds;
-            GSS_TRY(launch_mstep_k(ctx, K, a, F));
+            GSS_TRY(launch_mstep_k(ctx, K, a, Yn, F));
             GSS_TRY(eig());
         }
     }
