@@ -546,30 +546,70 @@ __device__ __forceinline__ void tri_unpack(int e, int D, int &d1, int &d2) {
     d2 = d1 + rem;
 }
 
-// B_k = D * (sum over chunks of the partial sums) / max(sum gamma, tiny), lower
-// triangle (and the mirrored upper one if `full`) into LDS; returns tr(B).
-__device__ inline double load_covariance(const cplx *__restrict__ Bp, int nch, int D, int K, int k,
-                                         int f, double den, double shift, bool full, cplx *A,
-                                         int ld, int lane) {
+// B_k = D * (sum over chunks of the partial sums) / max(sum gamma, tiny): every lane
+// reduces its packed entries e = lane, lane + 64, ... into `vals` (at most
+// COV_SLOTS = ceil(528 / 64) of them).  All chunk loads of an entry are issued before
+// they are summed -- the reduction is otherwise a chain of dependent L2 round trips.
+constexpr int COV_SLOTS = 9;
+
+__device__ inline double reduce_covariance(const cplx *__restrict__ Bp, int nch, int D, int K,
+                                           int k, int f, double den, cplx (&vals)[COV_SLOTS],
+                                           int lane) {
     const int NE = tri_count(D);
     double tr = 0.0;
-    for (int e = lane; e < NE; e += 64) {
-        int d1, d2;
-        tri_unpack(e, D, d1, d2);
+#pragma unroll
+    for (int s = 0; s < COV_SLOTS; ++s) {
+        const int e = lane + 64 * s;
         cplx v = c_make(0.0, 0.0);
-        for (int c = 0; c < nch; ++c)
-            v = c_add(v, Bp[(((int64_t)f * nch + c) * K + k) * NE + e]);
-        v.x = ((double)D * v.x) / den;
-        v.y = ((double)D * v.y) / den;
-        if (d1 == d2) {
-            v.y = 0.0;
-            tr += v.x;
-            v.x -= shift;
+        if (e < NE) {
+            const cplx *src = Bp + ((int64_t)f * nch * K + k) * NE + e;
+            int c = 0;
+            for (; c + 8 <= nch; c += 8) {
+                cplx t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = src[(int64_t)(c + j) * K * NE];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v = c_add(v, t[j]);
+            }
+            for (; c < nch; ++c) v = c_add(v, src[(int64_t)c * K * NE]);
+            v.x = ((double)D * v.x) / den;
+            v.y = ((double)D * v.y) / den;
         }
-        A[d2 * ld + d1] = c_conj(v);            // lower triangle: B[d2][d1] = conj(B[d1][d2])
-        if (full) A[d1 * ld + d2] = v;
+        vals[s] = v;
+    }
+    // trace: diagonal entries
+#pragma unroll
+    for (int s = 0; s < COV_SLOTS; ++s) {
+        const int e = lane + 64 * s;
+        if (e < NE) {
+            int d1, d2;
+            tri_unpack(e, D, d1, d2);
+            if (d1 == d2) {
+                vals[s].y = 0.0;
+                tr += vals[s].x;
+            }
+        }
     }
     return wave_sum(tr);
+}
+
+// Scatter the reduced entries into LDS: lower triangle (conjugated), optionally the
+// mirrored upper one, with `shift` subtracted from the diagonal.
+__device__ inline void store_covariance(const cplx (&vals)[COV_SLOTS], int D, double shift,
+                                        bool full, cplx *A, int ld, int lane) {
+    const int NE = tri_count(D);
+#pragma unroll
+    for (int s = 0; s < COV_SLOTS; ++s) {
+        const int e = lane + 64 * s;
+        if (e < NE) {
+            int d1, d2;
+            tri_unpack(e, D, d1, d2);
+            cplx v = vals[s];
+            if (d1 == d2) v.x -= shift;
+            A[d2 * ld + d1] = c_conj(v);
+            if (full) A[d1 * ld + d2] = v;
+        }
+    }
 }
 
 // grid (K, F), block 64 (one wave per class matrix).
@@ -602,17 +642,17 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
     if (lane == 0) pi[f * K + k] = sg / (double)T;
 
     // certificate: B - floor * tr(B) * I positive definite
-    double tr = load_covariance(Bp, nch, D, K, k, f, den, 0.0, false, A, ld, lane);
+    cplx vals[COV_SLOTS];
+    const double tr = reduce_covariance(Bp, nch, D, K, k, f, den, vals, lane);
     bool fast = !force_eigh && tr > 0.0 && isfinite(tr);
     if (fast) {
-        __syncthreads();
-        for (int i = lane; i < D; i += 64) A[i * ld + i].x -= eig_floor * tr;
+        store_covariance(vals, D, eig_floor * tr, false, A, ld, lane);
         __syncthreads();
         fast = cholesky_lower_wave(A, D, ld, lane);
     }
     if (fast) {
         __syncthreads();
-        load_covariance(Bp, nch, D, K, k, f, den, 0.0, false, A, ld, lane);
+        store_covariance(vals, D, 0.0, false, A, ld, lane);
         __syncthreads();
         fast = cholesky_lower_wave(A, D, ld, lane);   // B itself is PD a fortiori
     }
@@ -663,7 +703,9 @@ __global__ __launch_bounds__(64) void em_eigh_kernel(const cplx *__restrict__ Bp
     const double den = fmax(sg, GSS_TINY);
     for (int idx = lane; idx < m * m; idx += 64) A[idx] = c_make(0.0, 0.0);
     __syncthreads();
-    load_covariance(Bp, nch, D, K, k, f, den, 0.0, true, A, m, lane);
+    cplx vals[COV_SLOTS];
+    reduce_covariance(Bp, nch, D, K, k, f, den, vals, lane);
+    store_covariance(vals, D, 0.0, true, A, m, lane);
     __syncthreads();
     jacobi_eigh_wave(A, V, m, lane, 20);
     double lmax = -INFINITY;
