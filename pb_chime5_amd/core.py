@@ -103,10 +103,16 @@ class GSS:
         return posterior
 
 
+def _original(value):
+    # CHiME-5 examples carry {'original': ..., 'observation': {...}} (core.py:218-219),
+    # CHiME-6 examples plain integers (core_chime6.py:215-216)
+    return value['original'] if isinstance(value, dict) else value
+
+
 def start_end_context_samples(ex):
     """The sample counts core.py:218-222 derives from ``ex`` (asserted >= 0)."""
-    start_context_samples = ex['start_orig']['original'] - ex['start']['original']
-    end_context_samples = ex['end']['original'] - ex['end_orig']['original']
+    start_context_samples = _original(ex['start_orig']) - _original(ex['start'])
+    end_context_samples = _original(ex['end']) - _original(ex['end_orig'])
     assert start_context_samples >= 0, (start_context_samples, ex)
     assert end_context_samples >= 0, (end_context_samples, ex)
     return start_context_samples, end_context_samples

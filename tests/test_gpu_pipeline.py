@@ -272,3 +272,77 @@ def test_config2_properties(gpu_ctx, config2_run):
     # the target is enhanced relative to the interferers: output power in the
     # target-only region vs. the region where the target is silent
     assert np.std(x_hat) > 0
+
+
+# ---------------------------------------------------------------- edge cases
+def _run_both(u, **kw):
+    from pb_chime5_amd import ops
+    cs = u.ex['start_orig']['original']
+    ce = u.ex['end']['original'] - u.ex['end_orig']['original']
+    got, det = ops.enhance_observation(u.obs, u.activity_array, u.target_index, cs, ce,
+                                       debug=True, **kw)
+    want, wdet = oracle.enhance_observation(u.obs, u.activity_array, u.target_index, u.ex,
+                                            return_details=True,
+                                            gss_fn=oracle.gss_block_batched, **kw)
+    return got, det, want, wdet
+
+
+def test_edge_very_short_utterance(gpu_ctx):
+    """Fewer frames than channels: every class covariance is rank deficient, the
+    1e-10 eigenvalue floor decides (eigendecomposition path)."""
+    from pb_chime5_amd import synthetic
+    u = synthetic.make_utterance(3, 4, 700, [(100, 600), (0, 400)], rir_taps=64)
+    got, det, want, wdet = _run_both(u, wpe=False, bss_iterations=4)
+    assert det['Obs'].shape[1] == 6 == wdet['Obs'].shape[1]
+    assert got.shape == want.shape
+    assert np.array_equal(det['acitivity_freq'], wdet['activity_freq'])
+    assert np.max(np.abs(det['posterior'] - np.where(wdet['masks'] == 0, det['posterior'],
+                                                      wdet['masks']))) < 1e-4
+
+
+def test_edge_target_never_active_and_silent_speaker(gpu_ctx):
+    from pb_chime5_amd import synthetic
+    u = synthetic.tiny(seed=5, num_channels=4, num_samples=9000, num_speakers=3, context=1024)
+    u.activity['P01'][:] = False          # target has no activity at all
+    u.activity['P03'][:] = False
+    got, det, want, wdet = _run_both(u, wpe=True, wpe_taps=3, bss_iterations=4)
+    assert det['ref_channel'] == wdet['ref_channel']
+    assert rel_err(np.abs(det['X_hat']), np.abs(wdet['X_hat'])) < TOL_STFT_MAG
+    assert rel_err(got, want) < 1e-4
+
+
+def test_edge_all_zero_observation_gives_nan_like_reference(gpu_ctx):
+    """Digital silence: PSD matrices are zero, solve falls back to lstsq -> w = 0, and
+    BAN divides 0 / 0 (eps = 0 upstream), so the reference returns NaN everywhere."""
+    from pb_chime5_amd import synthetic
+    u = synthetic.tiny(num_channels=3, num_samples=6000, num_speakers=2, context=512)
+    u.obs[:] = 0
+    got, det, want, wdet = _run_both(u, wpe=True, wpe_taps=2, bss_iterations=2)
+    assert np.all(np.isnan(want)) and np.all(np.isnan(got))
+
+
+def test_edge_single_class_and_two_channels(gpu_ctx):
+    from pb_chime5_amd import ops
+    rng = np.random.default_rng(12)
+    obs = rng.standard_normal((2, 5000))
+    act = np.ones((1, 5000), bool)
+    ex = {'start': {'original': 0}, 'start_orig': {'original': 0},
+          'end_orig': {'original': 5000}, 'end': {'original': 5000}}
+    got, det = ops.enhance_observation(obs, act, 0, 0, 0, wpe=True, wpe_taps=2,
+                                       bss_iterations=2, debug=True)
+    want, wdet = oracle.enhance_observation(obs, act, 0, ex, wpe_taps=2, bss_iterations=2,
+                                            return_details=True,
+                                            gss_fn=oracle.gss_block_batched)
+    # one class: posteriors are exactly 1, the distortion mask is 0 -> lstsq path -> NaN
+    assert np.all(det['posterior'] == 1.0) and np.all(wdet['masks'][0][3:-3] == 1.0)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+
+
+def test_unsupported_sizes_fail_loudly(gpu_ctx):
+    from pb_chime5_amd import ops
+    with pytest.raises(NotImplementedError):
+        ops.enhance_observation(np.zeros((2, 4000)), np.ones((9, 4000), bool), 0, 0, 0)
+    with pytest.raises(NotImplementedError):
+        ops.stft(np.zeros(4000), size=1000, shift=250)
+    with pytest.raises(ValueError):
+        ops.enhance_observation(np.zeros((2, 4000)), np.ones((2, 100), bool), 0, 0, 0)

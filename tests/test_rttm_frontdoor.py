@@ -1,0 +1,131 @@
+"""RTTM-driven front door (core_chime6_rttm): integer / string logic on the CPU, and
+one end-to-end session on the GPU checked against the oracle."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+RTTM = """SPEAKER S02_U06.ENH 1 0.50 1.25 <NA> <NA> P05 <NA>
+SPEAKER S02_U06.ENH 1 2.00 0.75 <NA> <NA> P05 <NA>
+SPEAKER S02_U06.ENH 1 1.00 1.50 <NA> <NA> P06 <NA>
+SPEAKER S09_U06 1 0.00 0.10 <NA> <NA> P25 <NA>
+"""
+
+
+def _make_chime6_dir(tmp_path, num_samples=52000, arrays=('U01', 'U02', 'U03')):
+    from pb_chime5_amd.io import dump_audio
+    rng = np.random.default_rng(7)
+    root = tmp_path / 'CHiME6'
+    audio = {}
+    (root / 'transcriptions' / 'dev').mkdir(parents=True)
+    (root / 'transcriptions' / 'dev' / 'S02.json').write_text('[]')
+    for a_i, a in enumerate(arrays):
+        for ch in range(1, 5):
+            n = num_samples - 37 * a_i            # files of different length
+            x = rng.standard_normal(n) * 0.05
+            path = root / 'audio' / 'dev' / f'S02_{a}.CH{ch}.wav'
+            dump_audio(x, path, normalize=False)
+            audio[path.name] = np.rint(x * 2 ** 15).clip(-2 ** 15, 2 ** 15 - 1) / 2 ** 15
+    rttm = tmp_path / 'dev_rttm'
+    rttm.write_text(RTTM)
+    return root, rttm, audio
+
+
+def test_from_rttm_is_sample_exact(tmp_path):
+    from pb_chime5_amd.database.chime5 import rttm
+    p = tmp_path / 'x.rttm'
+    p.write_text(RTTM)
+    data = rttm.strip_file_id(rttm.from_rttm(p))
+    assert sorted(data) == ['S02', 'S09']
+    assert data['S02']['P05'].normalized_intervals == ((8000, 28000), (32000, 44000))
+    assert data['S02']['P06'].normalized_intervals == ((16000, 40000),)
+    assert data['S02']['P05'][7999:8002].tolist() == [False, True, True]
+    # reference doctest (utils/intervall_array.py:45-58)
+    q = tmp_path / 'd.rttm'
+    q.write_text('SPEAKER S02 1 0 1 <NA> <NA> 1 <NA>\nSPEAKER S02 1 2 1 <NA> <NA> 1 <NA>\n'
+                 'SPEAKER S02 1 0 2 <NA> <NA> 2 <NA>')
+    d = rttm.from_rttm(q)
+    assert repr(d['S02']['1']) == 'ArrayIntervall("0:16000, 32000:48000", shape=None)'
+    assert repr(d['S02']['2']) == 'ArrayIntervall("0:32000", shape=None)'
+    assert rttm.ones()[5:9].tolist() == [True] * 4 and rttm.zeros()[5:9].tolist() == [False] * 4
+    # non-integer sample positions are refused like in the reference
+    bad = tmp_path / 'bad.rttm'
+    bad.write_text('SPEAKER S02 1 0.00001 1 <NA> <NA> 1 <NA>')
+    with pytest.raises(AssertionError):
+        rttm.from_rttm(bad)
+
+
+def test_database_examples_context_and_audio(tmp_path):
+    from pb_chime5_amd.database.chime5 import rttm
+    from pb_chime5_amd.core_chime6_rttm import get_database
+    root, rttm_file, audio = _make_chime6_dir(tmp_path)
+    assert rttm.RTTMDatabase.example_id('S02', '1', 100, 200) == 'S02_U06.-1-000000100_000000200'
+    files = rttm.get_chime6_files(root, worn=False, flat=False)
+    assert list(files) == ['S02'] and list(files['S02']) == ['U01', 'U02', 'U03']
+    assert [len(v) for v in files['S02'].values()] == [4, 4, 4]
+    assert len(rttm.select_channels(root, True)['S02']) == 12
+    outer = rttm.select_channels(root, 'outer_array_mics')['S02']
+    assert [p.split('/')[-1] for p in outer] == [
+        'S02_U01.CH1.wav', 'S02_U01.CH4.wav', 'S02_U02.CH1.wav', 'S02_U02.CH4.wav',
+        'S02_U03.CH1.wav', 'S02_U03.CH4.wav']
+    assert len(rttm.select_channels(root, 'first_array_mics')['S02']) == 3
+    with pytest.raises(ValueError):
+        rttm.select_channels(root, 'nope')
+
+    db = get_database(root, rttm_file, 'outer_array_mics')
+    assert 'dev' in db.dataset_names
+    ds = db.get_dataset_for_session('dev', audio_read=True, context_samples=4000)
+    ids = [e['example_id'] for e in ds.examples]
+    assert ids == ['S02_U06.-P05-000008000_000028000', 'S02_U06.-P05-000032000_000044000',
+                   'S02_U06.-P06-000016000_000040000']
+    ex = ds[1]
+    assert (ex['start'], ex['end'], ex['start_orig'], ex['end_orig'], ex['num_samples_orig']) == \
+        (28000, 48000, 32000, 44000, 12000)
+    assert ex['audio_data'].shape == (6, 20000) and ex['audio_data'].dtype == np.float64
+    assert np.array_equal(ex['audio_data'][1], audio['S02_U01.CH4.wav'][28000:48000])
+    # context is clipped at the start of the recording, files are cut to the shortest
+    ds = db.get_dataset_for_session('S02', audio_read=True, context_samples=(10000, 9000))
+    ex = ds[0]
+    assert (ex['start'], ex['end']) == (0, 37000) and ex['start_orig'] == 8000
+    ex = ds[1]
+    assert ex['end'] == 53000 and ex['audio_data'].shape == (6, 52000 - 74 - 22000)
+
+
+@pytest.mark.gpu
+def test_enhance_session_end_to_end_vs_oracle(gpu_ctx, tmp_path):
+    import gss_oracle as oracle
+    from pb_chime5_amd.io import load_audio
+    from pb_chime5_amd.scripts import enhance_rttm
+    root, rttm_file, _ = _make_chime6_dir(tmp_path)
+    out = tmp_path / 'out'
+    enhance_rttm.main([
+        '--chime6-dir', str(root), '--database-rttm', str(rttm_file), '--session-id', 'S02',
+        '--out', str(out), '--context-samples', '4000', '--wpe-tabs', '2',
+        '--bss-iterations', '3', '--multiarray', 'first_array_mics'])
+    wavs = sorted((out / 'audio' / 'dev').glob('*.wav'))
+    assert [w.name for w in wavs] == [
+        'S02_U06.-P05-000008000_000028000.wav', 'S02_U06.-P05-000032000_000044000.wav',
+        'S02_U06.-P06-000016000_000040000.wav']
+    # recompute example 2 with the oracle from the same inputs
+    from pb_chime5_amd.core_chime6_rttm import get_enhancer
+    enh = get_enhancer(database_rttm=[str(rttm_file)], activity_rttm=[str(rttm_file)],
+                       chime6_dir=root, multiarray='first_array_mics', context_samples=4000,
+                       wpe_tabs=2, bss_iterations=3)
+    ex = enh.get_dataset('S02')[1]
+    act = {k: v[ex['start']:ex['end']] for k, v in enh.activity['S02'].items()}
+    assert list(act) == ['P05', 'P06', 'Noise'] and act['Noise'].all()
+    oex = {'start': {'original': ex['start']}, 'start_orig': {'original': ex['start_orig']},
+           'end_orig': {'original': ex['end_orig']}, 'end': {'original': ex['end']}}
+    want = oracle.enhance_observation(ex['audio_data'], np.array(list(act.values())), 0, oex,
+                                      wpe_taps=2, bss_iterations=3,
+                                      gss_fn=oracle.gss_block_batched)
+    want = want[4000:4000 + 12000]
+    got = enh.enhance_example(ex)
+    assert got.shape == want.shape == (12000,)
+    assert rel_err(got, want) < 1e-6
+    # the file holds the peak-normalised 16-bit version of the same signal
+    pcm = load_audio(wavs[1])
+    ref = want * ((2 ** 15 - 1) / 2 ** 15 / np.max(np.abs(want)))
+    assert np.max(np.abs(pcm - ref)) <= 1.01 / 2 ** 15
