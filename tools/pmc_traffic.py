@@ -25,7 +25,7 @@ BENCH_NAME = {
     'chol_backsolve_kernel': 'wpe_backsolve', 'em_chol_kernel': 'em_chol',
     'em_eigh_kernel': 'em_eigh', 'stft_kernel': 'stft', 'mvdr_apply_kernel': 'mvdr_apply',
     'mvdr_solve_kernel': 'mvdr_solve', 'istft_frames_kernel': 'istft_frames',
-    'istft_ola_kernel': 'istft_ola', 'masks_kernel': 'masks',
+    'istft_ola_kernel': 'istft_ola', 'masks_kernel': 'masks', 'em_prepare_kernel': 'em_prepare',
 }
 
 
@@ -37,8 +37,12 @@ def bench_name(kernel):
     if base == 'em_estep_kernel':
         mode = targs.split(',')[1].strip()
         return {'0': 'em_estep_first', '1': 'em_estep', '2': 'em_predict'}[mode]
+    if base == 'em_estep_reg_kernel':
+        mode = targs.split(',')[2].strip()
+        return {'1': 'em_estep', '2': 'em_predict'}[mode]
     if base == 'wcov_kernel':
-        return 'em_mstep' if 'true' in targs else 'psd'
+        k = targs.split(',')[0].strip()
+        return 'psd' if (k == '2' and 'false, false' in targs) else 'em_mstep'
     return BENCH_NAME.get(base)
 
 
