@@ -88,19 +88,44 @@ __global__ __launch_bounds__(256) void wpe_corr_kernel(
             t3[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
         }
 
-    for (int64_t t0 = 0; t0 < T; t0 += CORR_KT) {
-        __syncthreads();
-        // stage frames [t0 - c, t0 - c + frames_lds) of Yflat, zero outside [0, T)
+    // The window of chunk i+1 is fetched from global memory into registers before the
+    // MFMAs of chunk i are issued and written to LDS after them, so the global-load
+    // latency hides under the matrix work (elements beyond CORR_STG * 256 -- only for
+    // very wide windows -- are staged synchronously).
+    constexpr int CORR_STG = 8;
+    const int total = frames_lds * D;
+    cplx stg[CORR_STG];
+    double stg_w = 0.0;
+    auto stage_load = [&](int64_t t0) {
         const int64_t fr0 = t0 - c;
-        for (int idx = threadIdx.x; idx < frames_lds * D; idx += blockDim.x) {
+#pragma unroll
+        for (int s = 0; s < CORR_STG; ++s) {
+            const int idx = threadIdx.x + 256 * s;
             const int64_t fr = fr0 + idx / D;
-            cplx v = c_make(0.0, 0.0);
-            if (fr >= 0 && fr < T) v = Yf[fr0 * D + idx];
-            S[idx] = v;
+            stg[s] = c_make(0.0, 0.0);
+            if (idx < total && fr >= 0 && fr < T) stg[s] = Yf[fr0 * D + idx];
         }
-        for (int k = threadIdx.x; k < CORR_KT; k += blockDim.x)
-            wS[k] = (t0 + k < T) ? wf[t0 + k] : 0.0;
+        if (threadIdx.x < CORR_KT) stg_w = (t0 + threadIdx.x < T) ? wf[t0 + threadIdx.x] : 0.0;
+    };
+    auto stage_store = [&](int64_t t0) {
+#pragma unroll
+        for (int s = 0; s < CORR_STG; ++s) {
+            const int idx = threadIdx.x + 256 * s;
+            if (idx < total) S[idx] = stg[s];
+        }
+        if (threadIdx.x < CORR_KT) wS[threadIdx.x] = stg_w;
+        const int64_t fr0 = t0 - c;
+        for (int idx = threadIdx.x + 256 * CORR_STG; idx < total; idx += blockDim.x) {
+            const int64_t fr = fr0 + idx / D;
+            S[idx] = (fr >= 0 && fr < T) ? Yf[fr0 * D + idx] : c_make(0.0, 0.0);
+        }
+    };
+    stage_load(0);
+    for (int64_t t0 = 0; t0 < T; t0 += CORR_KT) {
+        __syncthreads();          // every wave is done with the previous chunk
+        stage_store(t0);
         __syncthreads();
+        if (t0 + CORR_KT < T) stage_load(t0 + CORR_KT);
         if (!active) continue;
         const int ksteps = CORR_KT / 4;
         // operands of k-step ks+1 are fetched from LDS while the MFMAs of ks run
