@@ -150,6 +150,14 @@ int gss_mvdr_souden(gss_ctx *ctx, const gss_cplx *Y_dev, int F, int64_t T, int D
                     const double *distortion_mask_dev, int ban,
                     gss_cplx *Xhat_dev, int32_t *ref_channel_dev);
 
+/* beamform_gev_from_masks (beamforming_wrapper.py:77-89,192-208): masked PSD
+ * matrices, principal generalised eigenvector of (Phi_X, Phi_N) with
+ * w^H Phi_N w = 1 (phase arbitrary, as upstream), optional BAN, apply.
+ * Y (F,T,D), masks (F,T) -> Xhat (T,F). */
+int gss_gev(gss_ctx *ctx, const gss_cplx *Y_dev, int F, int64_t T, int D,
+            const double *target_mask_dev, const double *distortion_mask_dev,
+            int ban, gss_cplx *Xhat_dev);
+
 /* Layout helpers between the canonical device layouts and the reference's. */
 int gss_layout_dtf_to_ftd(gss_ctx *ctx, const gss_cplx *src_dev, int D, int64_t T,
                           int F, gss_cplx *dst_dev);
@@ -174,7 +182,8 @@ typedef struct {
     int bss_iterations;       /* 20   */
     int bss_iterations_post;  /* 1    */
     int bf_drop_context;      /* 1    */
-    int bf;                   /* 0 = 'mvdrSouden_ban', 1 = 'ch2', 2 = 'sum'    */
+    int bf;                   /* 0 = 'mvdrSouden_ban', 1 = 'ch2', 2 = 'sum',   */
+                              /* 3 = 'gev_ban' (not in the reference's dispatch) */
     int postfilter;           /* 0 = None, 1 = 'mask_mul'                      */
 } gss_params;
 

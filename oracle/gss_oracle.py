@@ -483,6 +483,30 @@ def blind_analytic_normalization(vector, noise_psd_matrix, eps=0):
     return vector * normalization[..., None]
 
 
+def get_gev_vector(target_psd_matrix, noise_psd_matrix):
+    """pb_bss get_gev_vector (call site beamforming_wrapper.py:79): principal
+    generalised eigenvector of (Phi_X, Phi_N) per frequency, B-normalised like
+    scipy.linalg.eigh / Eigen's GeneralizedSelfAdjointEigenSolver; phase arbitrary."""
+    from scipy.linalg import eigh
+    F, D, _ = target_psd_matrix.shape
+    out = np.empty((F, D), dtype=np.complex128)
+    for f in range(F):
+        _, vecs = eigh(target_psd_matrix[f], noise_psd_matrix[f])
+        out[f] = vecs[:, -1]
+    return out
+
+
+def beamform_gev_from_masks(Y, X_mask, N_mask, ban=True):
+    """beamforming_wrapper.py:192-208 for Y (D,T,F) and 2-D masks (T,F)."""
+    Yf = Y.transpose(2, 0, 1)
+    cov_x = get_power_spectral_density_matrix(Yf, X_mask.T)
+    cov_n = get_power_spectral_density_matrix(Yf, N_mask.T)
+    w = get_gev_vector(cov_x, cov_n)
+    if ban:
+        w = blind_analytic_normalization(w, cov_n)
+    return apply_beamforming_vector(w, Yf).T
+
+
 def apply_beamforming_vector(vector, mix):
     """vector (F, D), mix (F, D, T) -> (F, T)."""
     return np.einsum('...a,...at->...t', vector.conj(), mix)
@@ -542,6 +566,8 @@ def enhance_observation(obs, activity, target_index, ex=None, *,
     if bf == 'mvdrSouden_ban':
         X_hat, details = beamform_mvdr_souden_from_masks(
             Obs, target_mask, distortion_mask, ban=True, return_details=True)
+    elif bf == 'gev_ban':
+        X_hat = beamform_gev_from_masks(Obs, target_mask, distortion_mask, ban=True)
     elif bf == 'ch2':
         X_hat = Obs[2]
     elif bf == 'sum':

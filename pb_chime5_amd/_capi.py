@@ -71,6 +71,8 @@ SIGNATURES = {
                 c_int64, c_void_p, c_void_p]),
     'gss_mvdr_souden': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int,
                                 c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'gss_gev': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int,
+                        c_void_p]),
     'gss_layout_dtf_to_ftd': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int,
                                       c_void_p]),
     'gss_layout_ftd_to_dtf': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int,

@@ -18,7 +18,7 @@ CSRC = PKG / 'csrc'
 LIB_DIR = PKG / 'lib'
 LIB_PATH = LIB_DIR / 'libgss_hip.so'
 SOURCES = ['gss_api.hip', 'stft.hip', 'wpe.hip', 'cacgmm.hip', 'mvdr.hip']
-HEADERS = ['gss_internal.h', 'jacobi.h', '../../include/gss_hip.h']
+HEADERS = ['gss_internal.h', 'jacobi.h', 'dense_wave.h', '../../include/gss_hip.h']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
          '-ffp-contract=on', '-fno-fast-math', '-Wall', '-Wno-unused-function']
 

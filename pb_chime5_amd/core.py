@@ -140,6 +140,13 @@ class Beamformer:
                 beamform_mvdr_souden_from_masks)
             X_hat = beamform_mvdr_souden_from_masks(
                 Y=Obs, X_mask=target_mask, N_mask=distortion_mask, ban=True)
+        elif bf == 'gev_ban':
+            # not selectable in the reference's Beamformer.__call__ (core.py:246-266); the
+            # GEV code path exists beside it (beamforming_wrapper.py:192-208)
+            from pb_chime5_amd.speech_enhancement.beamforming_wrapper import (
+                beamform_gev_from_masks)
+            X_hat = beamform_gev_from_masks(Y=Obs, X_mask=target_mask, N_mask=distortion_mask,
+                                            ban=True)
         elif bf == 'ch2':
             X_hat = Obs[2]
         elif bf == 'sum':

@@ -402,6 +402,17 @@ extern "C" int gss_mvdr_souden(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T
                     reinterpret_cast<cplx *>(Xhat), ref);
 }
 
+extern "C" int gss_gev(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T, int D, const double *mx,
+                       const double *mn, int ban, gss_cplx *Xhat) {
+    GSS_ENTER(ctx);
+    GSS_REQUIRE(ctx, Y && mx && mn && Xhat && F >= 1 && T >= 1, GSS_ERR_INVALID,
+                "gss_gev: bad arguments");
+    GSS_REQUIRE(ctx, D >= 1 && D < 30, GSS_ERR_INVALID, "assert D < 30 failed: D=%d", D);
+    GSS_TRY(arena_reserve(ctx, mvdr_workspace_bytes(F, T, D)));
+    return mvdr_run(ctx, reinterpret_cast<const cplx *>(Y), F, T, D, mx, mn, ban,
+                    reinterpret_cast<cplx *>(Xhat), nullptr, /*gev=*/1);
+}
+
 extern "C" int gss_selftest_mfma(gss_ctx *ctx) {
     GSS_ENTER(ctx);
     return selftest_mfma_run(ctx);
@@ -413,7 +424,7 @@ static int check_params(gss_ctx *ctx, const gss_params *p) {
     GSS_REQUIRE(ctx, p->stft_size == ctx->stft_size && p->stft_shift == ctx->stft_shift,
                 GSS_ERR_INVALID, "params stft %d/%d differ from gss_set_windows() %d/%d",
                 p->stft_size, p->stft_shift, ctx->stft_size, ctx->stft_shift);
-    GSS_REQUIRE(ctx, p->bf >= 0 && p->bf <= 2, GSS_ERR_UNSUPPORTED, "bf=%d", p->bf);
+    GSS_REQUIRE(ctx, p->bf >= 0 && p->bf <= 3, GSS_ERR_UNSUPPORTED, "bf=%d", p->bf);
     GSS_REQUIRE(ctx, p->postfilter >= 0 && p->postfilter <= 1, GSS_ERR_UNSUPPORTED,
                 "postfilter=%d", p->postfilter);
     return GSS_OK;
@@ -455,7 +466,7 @@ extern "C" int gss_enhance_observation(gss_ctx *ctx, const gss_params *p, const 
                 "assert context samples >= 0 failed: %lld %lld", (long long)start_ctx,
                 (long long)end_ctx);
     GSS_TRY(check_cacgmm_args(ctx, D, K, p->bss_iterations, p->bss_iterations_post));
-    if (p->bf == 0)
+    if (p->bf == 0 || p->bf == 3)
         GSS_REQUIRE(ctx, D < 30, GSS_ERR_INVALID, "assert D < 30 failed: D=%d", D);
     if (p->bf == 1)
         GSS_REQUIRE(ctx, D > 2, GSS_ERR_INVALID, "bf='ch2' needs more than 2 channels");
@@ -500,8 +511,8 @@ extern "C" int gss_enhance_observation(gss_ctx *ctx, const gss_params *p, const 
     }
     GSS_TRY(masks_from_posteriors_run(ctx, gamma, F, K, T, target, p->bf_drop_context, sf, ef,
                                       mx, mn));
-    if (p->bf == 0) {
-        GSS_TRY(mvdr_run(ctx, X, F, T, D, mx, mn, /*ban=*/1, Xhat, ref));
+    if (p->bf == 0 || p->bf == 3) {
+        GSS_TRY(mvdr_run(ctx, X, F, T, D, mx, mn, /*ban=*/1, Xhat, ref, /*gev=*/p->bf == 3));
         ctx->arena_off = mark;
     } else {
         GSS_TRY(channel_pick_run(ctx, X, F, T, D, p->bf, Xhat));
@@ -525,7 +536,7 @@ extern "C" int gss_enhance_observation(gss_ctx *ctx, const gss_params *p, const 
         GSS_TRY(cp(taps->target_mask, mx, sizeof(double) * (size_t)F * T));
         GSS_TRY(cp(taps->distortion_mask, mn, sizeof(double) * (size_t)F * T));
         GSS_TRY(cp(taps->Xhat, Xhat, sizeof(cplx) * (size_t)F * T));
-        if (p->bf == 0) GSS_TRY(cp(taps->ref_channel, ref, sizeof(int32_t)));
+        if (p->bf == 0 || p->bf == 3) GSS_TRY(cp(taps->ref_channel, ref, sizeof(int32_t)));
     }
     return GSS_OK;
 }

@@ -187,7 +187,7 @@ int psd_partials_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const
 
 size_t mvdr_workspace_bytes(int F, int64_t T, int D);
 int mvdr_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double *mx,
-             const double *mn, int ban, cplx *Xhat, int32_t *ref_channel);
+             const double *mn, int ban, cplx *Xhat, int32_t *ref_channel, int gev = 0);
 int masks_from_posteriors_run(gss_ctx *ctx, const double *gamma, int F, int K, int64_t T,
                               int target, int drop, int64_t start_frames,
                               int64_t end_frames, double *mx, double *mn);

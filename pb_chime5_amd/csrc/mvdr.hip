@@ -5,6 +5,7 @@
 //   -> pb_bss.extraction.beamformer.{get_power_spectral_density_matrix,
 //      get_mvdr_vector_souden(eps=1e-10), blind_analytic_normalization,
 //      apply_beamforming_vector}
+#include "dense_wave.h"
 #include "gss_internal.h"
 #include "jacobi.h"
 
@@ -263,6 +264,126 @@ __global__ __launch_bounds__(64) void mvdr_solve_kernel(
     }
 }
 
+// GEV beamformer (beamforming_wrapper.py:77-89 -> pb_bss get_gev_vector): principal
+// generalised eigenvector of (Phi_X, Phi_N), normalised like the generalised
+// Hermitian eigensolvers do (w^H Phi_N w = 1; the phase is arbitrary, as upstream).
+//   Phi_N = L L^H,  C = L^-1 Phi_X L^-H,  C u = lambda_max u,  w = L^-H u
+// One wave per frequency; w is written to column 0 of W so that mvdr_apply (with
+// ref = 0) does the BAN and the filtering.  A Phi_N that is not positive definite
+// yields NaN (the reference raises LinAlgError there).
+__global__ __launch_bounds__(64) void gev_solve_kernel(const cplx *__restrict__ part,
+                                                       const double *__restrict__ msum, int nch,
+                                                       int D, cplx *__restrict__ Phi,
+                                                       cplx *__restrict__ W,
+                                                       int32_t *__restrict__ ref) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int m = D + (D & 1);
+    const int NE = tri_count(D);
+    cplx *Ln = reinterpret_cast<cplx *>(smem);    // m * m : Phi_N -> L -> L^-1
+    cplx *JA = Ln + m * m;                         // m * m : C
+    cplx *JV = JA + m * m;                         // m * m : eigenvectors
+    cplx *Tm = JV + m * m;                         // m * m : Linv Phi_X
+    const int f = blockIdx.x, lane = threadIdx.x;
+    if (f == 0 && lane == 0) ref[0] = 0;
+
+    const double dx = fmax(msum[f * 2], 1e-10), dn = fmax(msum[f * 2 + 1], 1e-10);
+    cplx *PhiX = Phi + (int64_t)f * 2 * D * D;
+    cplx *PhiN = PhiX + D * D;
+    for (int idx = lane; idx < m * m; idx += 64) {
+        Ln[idx] = c_make(0.0, 0.0);
+        JA[idx] = c_make(0.0, 0.0);
+    }
+    __syncthreads();
+    for (int e = lane; e < NE; e += 64) {
+        int d1 = 0, rem = e;
+        while (rem >= D - d1) {
+            rem -= D - d1;
+            ++d1;
+        }
+        const int d2 = d1 + rem;
+        cplx vx = c_make(0.0, 0.0), vn = c_make(0.0, 0.0);
+        for (int c = 0; c < nch; ++c) {
+            const cplx *pp = part + ((int64_t)f * nch + c) * 2 * NE;
+            vx = c_add(vx, pp[e]);
+            vn = c_add(vn, pp[NE + e]);
+        }
+        vx = c_make(vx.x / dx, vx.y / dx);
+        vn = c_make(vn.x / dn, vn.y / dn);
+        if (d1 == d2) {
+            vx.y = 0.0;
+            vn.y = 0.0;
+        }
+        PhiX[d1 * D + d2] = vx;
+        PhiX[d2 * D + d1] = c_conj(vx);
+        PhiN[d1 * D + d2] = vn;
+        PhiN[d2 * D + d1] = c_conj(vn);
+        Ln[d2 * m + d1] = c_conj(vn);          // lower triangle
+        if (d1 == d2) Ln[d1 * m + d1] = vn;
+    }
+    __syncthreads();
+    cplx *Wf = W + (int64_t)f * D * D;
+    if (!cholesky_lower_wave(Ln, D, m, lane)) {
+        for (int idx = lane; idx < D * D; idx += 64) Wf[idx] = c_make(NAN, NAN);
+        return;
+    }
+    invert_lower_wave(Ln, D, m, lane);          // Ln = L^-1 (lower)
+    // Tm = Linv Phi_X
+    for (int idx = lane; idx < D * D; idx += 64) {
+        const int i = idx / D, j = idx - i * D;
+        cplx v = c_make(0.0, 0.0);
+        for (int k = 0; k <= i; ++k) c_fma(v, Ln[i * m + k], PhiX[k * D + j]);
+        Tm[i * m + j] = v;
+    }
+    __syncthreads();
+    // C = Tm Linv^H  (Hermitian)
+    for (int idx = lane; idx < D * D; idx += 64) {
+        const int i = idx / D, j = idx - i * D;
+        cplx v = c_make(0.0, 0.0);
+        for (int k = 0; k <= j; ++k) c_fmac(v, Tm[i * m + k], Ln[j * m + k]);
+        JA[i * m + j] = v;
+    }
+    __syncthreads();
+    // exact Hermitian symmetry for the Jacobi sweeps
+    for (int idx = lane; idx < D * D; idx += 64) {
+        const int i = idx / D, j = idx - i * D;
+        if (i < j) {
+            const cplx a = JA[i * m + j], b = JA[j * m + i];
+            const cplx h = c_make(0.5 * (a.x + b.x), 0.5 * (a.y - b.y));
+            Tm[i * m + j] = h;
+            Tm[j * m + i] = c_conj(h);
+        } else if (i == j) {
+            Tm[i * m + i] = c_make(JA[i * m + i].x, 0.0);
+        }
+    }
+    __syncthreads();
+    for (int idx = lane; idx < m * m; idx += 64) {
+        const int i = idx / m, j = idx - i * m;
+        JA[idx] = (i < D && j < D) ? Tm[idx] : c_make(0.0, 0.0);
+    }
+    __syncthreads();
+    jacobi_eigh_wave(JA, JV, m, lane, 20);
+    // largest eigenvalue (first index on ties)
+    double best = lane < D ? JA[lane * m + lane].x : -INFINITY;
+    int bi = lane < D ? lane : 1 << 30;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    // w = Linv^H u :  w[d] = sum_{i >= d} conj(Linv[i][d]) u[i]
+    for (int idx = lane; idx < D * D; idx += 64) {
+        const int d = idx / D, col = idx - d * D;
+        cplx v = c_make(0.0, 0.0);
+        if (col == 0)
+            for (int i = d; i < D; ++i) c_cfma(v, Ln[i * m + d], JV[i * m + bi]);
+        Wf[idx] = v;
+    }
+}
+
 // get_optimal_reference_channel: one reference channel for all frequencies.
 __global__ __launch_bounds__(64) void mvdr_ref_kernel(const cplx *__restrict__ snr, int F, int D,
                                                       double eps, int32_t *__restrict__ ref) {
@@ -394,7 +515,7 @@ size_t mvdr_workspace_bytes(int F, int64_t T, int D) {
 }
 
 int mvdr_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double *mx,
-             const double *mn, int ban, cplx *Xhat, int32_t *ref_channel) {
+             const double *mn, int ban, cplx *Xhat, int32_t *ref_channel, int gev) {
     const int NE = tri_count(D);
     int cf;
     const int nch = psd_chunks(F, T, &cf);
@@ -414,24 +535,37 @@ int mvdr_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double 
         GSS_LAUNCH_CHECK(ctx, "mask_pack_kernel");
         GSS_TRY(psd_partials_run(ctx, Y, F, T, D, W2, nch, cf, part));
     }
-    {
-        GSS_PROF(ctx, "mvdr_solve");
+    if (gev) {
+        GSS_PROF(ctx, "gev_solve");
         const int m = D + (D & 1);
-        const size_t lds = (sizeof(cplx) * ((size_t)D * 2 * D + 2 * (size_t)m * m) +
-                            16 + 15) / 16 * 16;
+        const size_t lds = (sizeof(cplx) * 4 * (size_t)m * m + 15) / 16 * 16;
         if (lds > 64 * 1024)
             GSS_HIP_CHECK(ctx, hipFuncSetAttribute(
-                                   reinterpret_cast<const void *>(mvdr_solve_kernel),
+                                   reinterpret_cast<const void *>(gev_solve_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(mvdr_solve_kernel, dim3(F), dim3(64), lds, ctx->stream, part, msum, nch,
-                           D, 1e-10, Phi, W, snr);
-        GSS_LAUNCH_CHECK(ctx, "mvdr_solve_kernel");
-    }
-    {
-        GSS_PROF(ctx, "mvdr_ref");
-        hipLaunchKernelGGL(mvdr_ref_kernel, dim3(1), dim3(64), 0, ctx->stream, snr, F, D, 1e-10,
-                           ref);
-        GSS_LAUNCH_CHECK(ctx, "mvdr_ref_kernel");
+        hipLaunchKernelGGL(gev_solve_kernel, dim3(F), dim3(64), lds, ctx->stream, part, msum, nch,
+                           D, Phi, W, ref);
+        GSS_LAUNCH_CHECK(ctx, "gev_solve_kernel");
+    } else {
+        {
+            GSS_PROF(ctx, "mvdr_solve");
+            const int m = D + (D & 1);
+            const size_t lds = (sizeof(cplx) * ((size_t)D * 2 * D + 2 * (size_t)m * m) +
+                                16 + 15) / 16 * 16;
+            if (lds > 64 * 1024)
+                GSS_HIP_CHECK(ctx, hipFuncSetAttribute(
+                                       reinterpret_cast<const void *>(mvdr_solve_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(mvdr_solve_kernel, dim3(F), dim3(64), lds, ctx->stream, part, msum, nch,
+                               D, 1e-10, Phi, W, snr);
+            GSS_LAUNCH_CHECK(ctx, "mvdr_solve_kernel");
+        }
+        {
+            GSS_PROF(ctx, "mvdr_ref");
+            hipLaunchKernelGGL(mvdr_ref_kernel, dim3(1), dim3(64), 0, ctx->stream, snr, F, D, 1e-10,
+                               ref);
+            GSS_LAUNCH_CHECK(ctx, "mvdr_ref_kernel");
+        }
     }
     {
         GSS_PROF(ctx, "mvdr_apply");

@@ -22,7 +22,7 @@ import numpy as np
 from . import _capi
 from ._capi import GssDebugTaps, GssParams, c_void_p, default_context
 
-_BF_CODES = {'mvdrSouden_ban': 0, 'ch2': 1, 'sum': 2}
+_BF_CODES = {'mvdrSouden_ban': 0, 'ch2': 1, 'sum': 2, 'gev_ban': 3}
 _POSTFILTER_CODES = {None: 0, 'mask_mul': 1}
 
 
@@ -211,6 +211,19 @@ def mvdr_souden_from_masks(Y, X_mask, N_mask, ban=False, *, return_ref_channel=F
     if return_ref_channel:
         return X_hat, int(ctx.to_host(ref_d, (1,), np.int32)[0])
     return X_hat
+
+
+def gev_from_masks(Y, X_mask, N_mask, ban=True, *, ctx=None):
+    """beamform_gev_from_masks: Y (D,T,F), 2-D masks (T,F) -> X_hat (T,F).  The phase
+    of a generalised eigenvector is arbitrary (upstream too); magnitudes are defined."""
+    ctx = ctx or default_context()
+    Y_d, (D, T, F) = _obs_to_device_ftd(ctx, Y)
+    mx = _mask_to_device_ft(ctx, X_mask, T, F)
+    mn = _mask_to_device_ft(ctx, N_mask, T, F)
+    X_d = ctx.empty(16 * F * T)
+    ctx._check(ctx.lib.gss_gev(ctx.handle, c_void_p(Y_d.ptr), F, T, D, c_void_p(mx.ptr),
+                               c_void_p(mn.ptr), int(bool(ban)), c_void_p(X_d.ptr)), 'gss_gev')
+    return ctx.to_host(X_d, (T, F), np.complex128)
 
 
 def activity_time_to_frequency_device(time_activity, size, shift, fading, *, ctx=None):

@@ -63,6 +63,29 @@ class _Beamformer:
     def ref_channel(self):
         return self._run(True)[1]
 
+    def _gev(self, ban):
+        key = ('gev', ban)
+        if key not in self._cache:
+            self._cache[key] = ops.gev_from_masks(
+                self.Y.transpose(1, 2, 0), self.X_mask.T, self.N_mask.T, ban=ban, ctx=self._ctx)
+        return self._cache[key]
+
+    @property
+    def X_hat_gev(self):
+        return self._gev(False)
+
+    @property
+    def X_hat_gev_ban(self):
+        return self._gev(True)
+
+
+def beamform_gev_from_masks(Y, X_mask, N_mask, ban=True, debug=False, ctx=None):
+    """beamforming_wrapper.py:192-208."""
+    bf = _Beamformer(Y=Y, X_mask=X_mask, N_mask=N_mask, debug=debug, ctx=ctx)
+    if ban:
+        return bf.X_hat_gev_ban
+    return bf.X_hat_gev
+
 
 def beamform_mvdr_souden_from_masks(Y, X_mask, N_mask, ban=False, debug=False, ctx=None):
     bf = _Beamformer(Y=Y, X_mask=X_mask, N_mask=N_mask, debug=debug, ctx=ctx)
