@@ -448,6 +448,49 @@ def make_enhance_example(core):
     return out
 
 
+def _chime5_example(shift=0):
+    arrays = ['U01', 'U02', 'U04']
+    ex = {
+        'audio_path': {'observation': {a: [f'{a}.CH{c}.wav' for c in range(1, 5)] for a in arrays},
+                       'worn_microphone': {'P05': 'P05.wav', 'P06': 'P06.wav'}},
+        'start': {'original': 649600 + shift,
+                  'observation': {'U01': 650080 + shift, 'U02': 650123 + shift, 'U04': 649001 + shift},
+                  'worn_microphone': {'P05': 649600 + shift, 'P06': 649700 + shift}},
+        'end': {'original': 701120 + shift,
+                'observation': {'U01': 701600 + shift, 'U02': 701650 + shift, 'U04': 700519 + shift},
+                'worn_microphone': {'P05': 701120 + shift, 'P06': 701110 + shift}},
+    }
+    ex['num_samples'] = {
+        k: (ex['end'][k] - ex['start'][k] if k == 'original' else
+            {a: ex['end'][k][a] - ex['start'][k][a] for a in ex['start'][k]})
+        for k in ex['start']}
+    return ex
+
+
+def make_context_bookkeeping():
+    """Reference backup_orig_start_end / adjust_start_end / AddContext on CHiME-5 shaped
+    examples (database.py:540-570, 706-1053)."""
+    import copy
+    from pb_chime5.database.chime5.database import (
+        backup_orig_start_end, adjust_start_end, AddContext)
+    cases = {}
+    for name, shift, samples, equal, adjust in [
+            ('plain', 0, 240000, False, False), ('equal', 0, 240000, True, False),
+            ('adjust_equal', 0, 240000, True, True), ('early', -640000, 16000, True, True),
+            ('early_plain', -640000, 16000, False, False), ('tuple', 0, (1000, 3), False, True)]:
+        ex = _chime5_example(shift)
+        inp = copy.deepcopy(ex)
+        ex = backup_orig_start_end(ex)
+        if adjust:
+            ex = adjust_start_end(ex)
+        ex = AddContext(samples, equal_start_context=equal)(ex)
+        cases[name] = {'input': inp, 'samples': samples, 'equal': equal, 'adjust': adjust,
+                       'output': {k: ex[k] for k in ('start', 'end', 'num_samples', 'start_orig',
+                                                     'end_orig', 'num_samples_orig')}}
+    (HERE / 'context_bookkeeping.json').write_text(json.dumps(cases, indent=1, default=int))
+    print('context_bookkeeping.json')
+
+
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         ref = _prepare_reference(Path(tmp))
@@ -468,6 +511,7 @@ def main():
         _save('wpe_block.npz', **make_wpe_block(core))
         _save('host_helpers.npz', **make_host_helpers(ref))
         _save('enhance_example.npz', **make_enhance_example(core))
+        make_context_bookkeeping()
 
 
 if __name__ == '__main__':

@@ -247,3 +247,26 @@ def test_windows_of_product_equal_oracle():
         a = ops.analysis_window(size)
         assert np.array_equal(a, oracle.blackman_periodic(size))
         assert np.array_equal(ops.synthesis_window(a, shift), oracle.biorthogonal_window(a, shift))
+
+
+def test_context_bookkeeping_fixture():
+    """backup_orig_start_end / adjust_start_end / AddContext against the reference's own
+    functions run on CHiME-5 shaped examples (database.py:540-570, 706-1053)."""
+    import copy
+    from conftest import GOLDEN
+    from pb_chime5_amd.database.chime5.context import (
+        AddContext, adjust_start_end, backup_orig_start_end)
+    cases = json.loads((GOLDEN / 'context_bookkeeping.json').read_text())
+    assert len(cases) == 6
+    for name, case in cases.items():
+        ex = copy.deepcopy(case['input'])
+        ex = backup_orig_start_end(ex)
+        if case['adjust']:
+            ex = adjust_start_end(ex)
+        samples = case['samples']
+        samples = tuple(samples) if isinstance(samples, list) else samples
+        ex = AddContext(samples, equal_start_context=case['equal'])(ex)
+        for key, want in case['output'].items():
+            assert ex[key] == want, (name, key)
+    with pytest.raises(AssertionError):
+        AddContext(-1)
