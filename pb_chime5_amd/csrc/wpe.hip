@@ -238,149 +238,191 @@ __global__ __launch_bounds__(256) void wpe_corr_kernel(
 // that row, which reproduces the minimum-norm lstsq fallback of stable_solve
 // (pb_chime5/math/solve.py:95-114) for zero rows / columns.
 constexpr int CH_NB = 48;
-constexpr int TRSM_COLS = 32;
+constexpr int UD_LD = CH_NB + 1;   // LDS leading dimension of the diagonal block (bank spread)
+
+// Factor the diagonal block at j0 of one frequency's matrix A (256 threads):
+// Ud <- U_JJ (upper) and W = U_JJ^-H (strictly lower), dinv <- 1 / diag(U_JJ); both are
+// also written back to A.  The block lives in REGISTERS, 3 x 3 entries per thread
+// (entry (i, k): i = ty + 16 a, k = tx + 16 b; upper part = trailing matrix / U, strictly
+// lower part = W under construction), and one sweep of nb right-looking steps builds U
+// and W together: per step the owners of row j publish it through LDS, ONE barrier,
+// then every thread reads the pivot, its 3 row and 3 column factors and updates its 9
+// entries.  The dependent chain is nb x (LDS round trip + rsqrt + 9 complex FMAs).
+__device__ inline void chol_diag_block(cplx *A, int n, int j0, cplx *Ud, double *dinv) {
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int nb = min(CH_NB, n - j0);
+    cplx reg[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int i = ty + 16 * a, k = tx + 16 * b;
+            reg[a][b] = (k >= i && k < nb) ? A[(int64_t)(j0 + i) * n + j0 + k] : c_make(0.0, 0.0);
+        }
+    for (int j = 0; j < nb; ++j) {
+        if (ty == (j & 15)) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                if (a == (j >> 4)) {
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) Ud[j * UD_LD + tx + 16 * b] = reg[a][b];
+                }
+        }
+        __syncthreads();
+        // all LDS reads of the step are issued together, unconditionally
+        const double ajj = Ud[j * UD_LD + j].x;
+        cplx ru[3], rv[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ru[a] = Ud[j * UD_LD + ty + 16 * a];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) rv[b] = Ud[j * UD_LD + tx + 16 * b];
+        double di = 0.0;
+        if (ajj > 0.0 && isfinite(ajj)) di = rsqrt(ajj);
+        if (tid == 0) dinv[j] = di;
+        cplx u[3], v[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            // conj(U[j][i]) for the rows below the pivot, 0 elsewhere
+            const double s = ty + 16 * a > j ? di : 0.0;
+            u[a] = c_make(ru[a].x * s, -ru[a].y * s);
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            // k > j: U[j][k];  k < j: W[j][k];  k == j: W[j][j] = 1 / U[j][j]
+            v[b] = tx + 16 * b == j ? c_make(di, 0.0) : c_scale(rv[b], di);
+        }
+        // entry (a, b) is an upper (U) entry when b > a, a W entry when b < a, and on
+        // a == b it depends on the thread; W entries only take columns k <= j
+        cplx vw[3], vd[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            vw[b] = tx + 16 * b <= j ? v[b] : c_make(0.0, 0.0);
+            vd[b] = tx >= ty ? v[b] : vw[b];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const cplx vv = b > a ? v[b] : (b < a ? vw[b] : vd[b]);
+                reg[a][b].x = fma(-u[a].x, vv.x, reg[a][b].x);
+                reg[a][b].x = fma(u[a].y, vv.y, reg[a][b].x);
+                reg[a][b].y = fma(-u[a].x, vv.y, reg[a][b].y);
+                reg[a][b].y = fma(-u[a].y, vv.x, reg[a][b].y);
+            }
+    }
+    __syncthreads();
+    // rows were published unscaled: scale them, fix the diagonal, clear the padding
+    for (int idx = tid; idx < CH_NB * CH_NB; idx += blockDim.x) {
+        const int i = idx / CH_NB, k = idx - i * CH_NB;
+        cplx r = c_make(0.0, 0.0);
+        if (i < nb && k < nb) {
+            const double di = dinv[i];
+            const cplx raw = Ud[i * UD_LD + k];
+            r = k == i ? c_make(di > 0.0 ? sqrt(raw.x) : 0.0, 0.0) : c_scale(raw, di);
+            A[(int64_t)(j0 + i) * n + j0 + k] = r;
+        }
+        Ud[i * UD_LD + k] = r;
+    }
+    __syncthreads();
+}
 
 __global__ __launch_bounds__(256) void chol_diag_kernel(cplx *__restrict__ R, int n, int j0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cplx *Ud = reinterpret_cast<cplx *>(smem);                       // CH_NB * CH_NB
-    double *dinv = reinterpret_cast<double *>(Ud + CH_NB * CH_NB);   // CH_NB
-    const int f = blockIdx.x, tid = threadIdx.x;
-    // thread (ty, tx): 16 x 16 grid over the block, 3 x 3 elements each at most
-    const int tx = tid & 15, ty = tid >> 4;
-    cplx *A = R + (int64_t)f * n * n;
-    const int nb = min(CH_NB, n - j0);
-
-    for (int i = ty; i < nb; i += 16)
-        for (int k = tx; k < nb; k += 16)
-            Ud[i * CH_NB + k] = k >= i ? A[(int64_t)(j0 + i) * n + j0 + k] : c_make(0.0, 0.0);
-    __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        const double a = Ud[j * CH_NB + j].x;
-        double d = 0.0, di = 0.0;
-        if (a > 0.0 && isfinite(a)) {
-            d = sqrt(a);
-            di = 1.0 / d;
-        }
-        // every thread scales the row entries it needs itself (no extra barrier):
-        // u_i = U[j][i] = A[j][i] * di for i > j
-        for (int i = j + 1 + ty; i < nb; i += 16) {
-            const cplx u = c_scale(Ud[j * CH_NB + i], di);
-            for (int k = i + ((tx - i) & 15); k < nb; k += 16) {      // k >= i, k = tx mod 16
-                const cplx w = c_scale(Ud[j * CH_NB + k], di);
-                cplx v = Ud[i * CH_NB + k];
-                v.x -= u.x * w.x + u.y * w.y;
-                v.y -= u.x * w.y - u.y * w.x;
-                Ud[i * CH_NB + k] = v;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            Ud[j * CH_NB + j] = c_make(d, 0.0);
-            dinv[j] = di;
-        }
-        for (int k = j + 1 + tid; k < nb; k += blockDim.x)
-            Ud[j * CH_NB + k] = c_scale(Ud[j * CH_NB + k], di);
-        __syncthreads();
-    }
-    // W = U^-H (lower triangular, W[i][i] = dinv[i]), right-looking forward
-    // substitution on all columns at once; the strictly lower triangle of Ud holds
-    // first the running right-hand sides (initially 0 off the diagonal), then W.
-    for (int i = 0; i < nb; ++i) {
-        // x_i[c] = v[i][c] * dinv[i] for c <= i  (v[i][i] = 1)
-        const double di = dinv[i];
-        for (int c = tid; c < i; c += blockDim.x)
-            Ud[i * CH_NB + c] = c_scale(Ud[i * CH_NB + c], di);
-        __syncthreads();
-        // v[m][c] -= conj(U[i][m]) x_i[c]  for m > i, c <= i
-        for (int m = i + 1 + ty; m < nb; m += 16) {
-            const cplx u = Ud[i * CH_NB + m];
-            for (int c = tx; c <= i; c += 16) {
-                const cplx x = c == i ? c_make(di, 0.0) : Ud[i * CH_NB + c];
-                cplx v = Ud[m * CH_NB + c];
-                v.x -= u.x * x.x + u.y * x.y;
-                v.y -= u.x * x.y - u.y * x.x;
-                Ud[m * CH_NB + c] = v;
-            }
-        }
-        __syncthreads();
-    }
-    for (int i = ty; i < nb; i += 16)
-        for (int k = tx; k < nb; k += 16) A[(int64_t)(j0 + i) * n + j0 + k] = Ud[i * CH_NB + k];
+    cplx *Ud = reinterpret_cast<cplx *>(smem);                       // CH_NB * UD_LD
+    double *dinv = reinterpret_cast<double *>(Ud + CH_NB * UD_LD);   // CH_NB
+    chol_diag_block(R + (int64_t)blockIdx.x * n * n, n, j0, Ud, dinv);
 }
 
-// U_J[:, cols] = W A_J[:, cols] for a chunk of TRSM_COLS trailing columns (or
-// right-hand sides).  grid (chunks, F), block 256.
+// Row panel on the MFMA: U_J[:, tile] = W A_J[:, tile] for one tile `ct` of 16 trailing
+// columns (tiles past the trailing block address the right-hand sides), by one wave.
+// The wave loads its nb x 16 block once (B operand, 12 k-steps), forms the three
+// 16-row output tiles (W is lower triangular: 4, 8 and 12 k-steps) and writes them
+// back in place.  W is read from the LDS copy of the diagonal block (strictly lower
+// part; the diagonal is taken from dinv, the upper part ignored).
+__device__ inline void chol_panel_tile(cplx *A, cplx *Z, int n, int D, int j0, int nb, int ct,
+                                       const cplx *Ud, const double *dinv, int lane) {
+    const int ntrail = n - j0 - nb;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nct_a = (ntrail + 15) / 16;
+    cplx *base;
+    int64_t stride;
+    int ncols;
+    if (ct < nct_a) {
+        base = A + (int64_t)j0 * n + j0 + nb + 16 * ct;
+        stride = n;
+        ncols = min(16, ntrail - 16 * ct);
+    } else {
+        base = Z + (int64_t)j0 * D + 16 * (ct - nct_a);
+        stride = D;
+        ncols = min(16, D - 16 * (ct - nct_a));
+    }
+    cplx bv[CH_NB / 4];
+#pragma unroll
+    for (int ks = 0; ks < CH_NB / 4; ++ks) {
+        const int row = 4 * ks + lk;
+        bv[ks] = (row < nb && li < ncols) ? base[row * stride + li] : c_make(0.0, 0.0);
+    }
+    v4d ore[3], oim[3];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        ore[it] = (v4d){0.0, 0.0, 0.0, 0.0};
+        oim[it] = (v4d){0.0, 0.0, 0.0, 0.0};
+        const int i = 16 * it + li;
+#pragma unroll
+        for (int ks = 0; ks < 4 * (it + 1); ++ks) {
+            const int k = 4 * ks + lk;
+            cplx w = Ud[i * UD_LD + k];
+            if (k == i) w = c_make(i < nb ? dinv[i] : 0.0, 0.0);
+            if (k > i) w = c_make(0.0, 0.0);
+            ore[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, bv[ks].x, ore[it], 0, 0, 0);
+            oim[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, bv[ks].y, oim[it], 0, 0, 0);
+            ore[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(-w.y, bv[ks].y, ore[it], 0, 0, 0);
+            oim[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.y, bv[ks].x, oim[it], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * it + lk + 4 * r;
+            if (row < nb && li < ncols) base[row * stride + li] = c_make(ore[it][r], oim[it][r]);
+        }
+}
+
+// grid (ceil(tiles / 4), F), block 256: every workgroup stages the factored diagonal
+// block of its frequency in LDS, then each wave takes one column tile.
 __global__ __launch_bounds__(256) void chol_trsm_kernel(cplx *__restrict__ R,
                                                         cplx *__restrict__ P, int n, int D,
                                                         int j0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cplx *W = reinterpret_cast<cplx *>(smem);            // CH_NB * CH_NB, lower incl. diagonal
-    cplx *As = W + CH_NB * CH_NB;                         // CH_NB * TRSM_COLS
+    cplx *Ud = reinterpret_cast<cplx *>(smem);                       // CH_NB * UD_LD
+    double *dinv = reinterpret_cast<double *>(Ud + CH_NB * UD_LD);   // CH_NB
     const int f = blockIdx.y, tid = threadIdx.x;
     cplx *A = R + (int64_t)f * n * n;
     cplx *Z = P + (int64_t)f * n * D;
     const int nb = min(CH_NB, n - j0);
     const int ntrail = n - j0 - nb;
-    const int c0 = blockIdx.x * TRSM_COLS;
-
     for (int idx = tid; idx < CH_NB * CH_NB; idx += blockDim.x) {
         const int i = idx / CH_NB, k = idx - i * CH_NB;
         cplx v = c_make(0.0, 0.0);
-        if (i < nb && k < nb) {
-            if (k < i) v = A[(int64_t)(j0 + i) * n + j0 + k];
-            else if (k == i) {
-                const double d = A[(int64_t)(j0 + i) * n + j0 + i].x;
-                v = c_make(d > 0.0 ? 1.0 / d : 0.0, 0.0);
-            }
-        }
-        W[idx] = v;
+        if (i < nb && k <= i) v = A[(int64_t)(j0 + i) * n + j0 + k];
+        Ud[i * UD_LD + k] = v;
+        if (k == i) dinv[i] = v.x > 0.0 ? 1.0 / v.x : 0.0;
     }
-    const int cl = tid & (TRSM_COLS - 1), rg = tid / TRSM_COLS;   // 8 row groups
-    const int c = c0 + cl;
-    const bool cvalid = c < ntrail + D;
-    cplx *col = nullptr;
-    int64_t stride = 0;
-    if (cvalid) {
-        if (c < ntrail) {
-            col = A + (int64_t)j0 * n + j0 + nb + c;
-            stride = n;
-        } else {
-            col = Z + (int64_t)j0 * D + (c - ntrail);
-            stride = D;
-        }
-    }
-    for (int i = rg; i < CH_NB; i += 256 / TRSM_COLS)
-        As[i * TRSM_COLS + cl] = (cvalid && i < nb) ? col[i * stride] : c_make(0.0, 0.0);
     __syncthreads();
-    constexpr int RPT = CH_NB / (256 / TRSM_COLS);   // rows per thread = 6
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        const int i = rg * RPT + r;
-        cplx v = c_make(0.0, 0.0);
-        for (int k = 0; k <= i; ++k) c_fma(v, W[i * CH_NB + k], As[k * TRSM_COLS + cl]);
-        if (cvalid && i < nb) col[i * stride] = v;
-    }
+    const int ct = blockIdx.x * 4 + (tid >> 6);
+    if (ct < (ntrail + 15) / 16 + (D + 15) / 16) chol_panel_tile(A, Z, n, D, j0, nb, ct, Ud, dinv, tid & 63);
 }
 
 struct UpdTile {
     int row_off, col_off, is_p, pad;
 };
 
-// grid (tile groups, F), block 256 = 4 waves, one (16 TM) x (16 TN) tile each.
+// Trailing update of one (16 TM) x (16 TN) tile by one wave:  C -= U_J^H U_J.
 template <int TM, int TN, bool PREFETCH>
-__global__ __launch_bounds__(256) void chol_update_kernel(cplx *__restrict__ R,
-                                                          cplx *__restrict__ P, int n, int D,
-                                                          int j0, int nb,
-                                                          const UpdTile *__restrict__ tiles,
-                                                          int ntiles) {
-    const int f = blockIdx.y;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile_id = blockIdx.x * 4 + wave;
-    if (tile_id >= ntiles) return;
-    const UpdTile tl = tiles[tile_id];
+__device__ inline void chol_update_tile(cplx *A, cplx *Z, int n, int D, int j0, int nb,
+                                        const UpdTile tl, int lane) {
     const int li = lane & 15, lk = lane >> 4;
-    cplx *A = R + (int64_t)f * n * n;
-    cplx *Z = P + (int64_t)f * n * D;
     const cplx *panel = A + (int64_t)j0 * n;      // rows j0 .. j0+nb of U
     const cplx *zpanel = Z + (int64_t)j0 * D;
     const int ncols = tl.is_p ? D : n;
@@ -477,20 +519,30 @@ __global__ __launch_bounds__(256) void chol_update_kernel(cplx *__restrict__ R,
             }
 }
 
+// grid (tile groups, F), block 256 = 4 waves, one tile each.
+template <int TM, int TN, bool PREFETCH>
+__global__ __launch_bounds__(256) void chol_update_kernel(cplx *__restrict__ R,
+                                                          cplx *__restrict__ P, int n, int D,
+                                                          int j0, int nb,
+                                                          const UpdTile *__restrict__ tiles,
+                                                          int ntiles) {
+    const int f = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile_id = blockIdx.x * 4 + wave;
+    if (tile_id >= ntiles) return;
+    chol_update_tile<TM, TN, PREFETCH>(R + (int64_t)f * n * n, P + (int64_t)f * n * D, n, D, j0,
+                                       nb, tiles[tile_id], lane);
+}
+
 // Blocked back substitution U G = Z, G overwrites Z:  G_J = W_J^H (Z_J - U_J,>J G_>J),
 // J descending, both products on the f64 MFMA.  grid (F), block 256: waves 0..2 own
 // one 16-row tile of the 48-row block each (2 column tiles = 32 right-hand sides per
 // pass), so every frequency reads its U exactly once.
 constexpr int BS_LD = 33;   // padded leading dimension of the LDS copy of S
 
-__global__ __launch_bounds__(256) void chol_backsolve_kernel(const cplx *__restrict__ R,
-                                                             cplx *__restrict__ P, int n, int D) {
-    __shared__ cplx S[CH_NB * BS_LD];
-    const int f = blockIdx.x;
+__device__ inline void chol_backsolve_body(const cplx *A, cplx *Z, int n, int D, cplx *S) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
-    const cplx *A = R + (int64_t)f * n * n;
-    cplx *Z = P + (int64_t)f * n * D;
     const int nblk = (n + CH_NB - 1) / CH_NB;
     const int a = wave;                       // row tile of this wave (waves 0..2)
     for (int c0 = 0; c0 < D; c0 += 32) {      // 32 right-hand sides per pass
@@ -595,6 +647,66 @@ __global__ __launch_bounds__(256) void chol_backsolve_kernel(const cplx *__restr
             __syncthreads();
         }
     }
+}
+
+__global__ __launch_bounds__(256) void chol_backsolve_kernel(const cplx *__restrict__ R,
+                                                             cplx *__restrict__ P, int n, int D) {
+    __shared__ cplx S[CH_NB * BS_LD];
+    const int f = blockIdx.x;
+    chol_backsolve_body(R + (int64_t)f * n * n, P + (int64_t)f * n * D, n, D, S);
+}
+
+// EXPERIMENT (GSS_SOLVE_FUSED=1): the whole solve of one frequency in ONE workgroup
+// (grid (F), block 256), the phases following each other inside the kernel.  One
+// launch instead of 14, but with F = 513 frequencies the chip holds only 2 workgroups
+// (8 waves) per CU and every phase runs at its latency: measured 1.34 ms per solve on
+// MI355X against 0.97 ms for the per-phase kernels below, whose grids are tiles x F.
+// Kept for shapes with many more frequencies than CUs x 3.
+__global__ __launch_bounds__(256, 3) void wpe_solve_fused_kernel(cplx *__restrict__ R,
+                                                              cplx *__restrict__ P, int n,
+                                                              int D) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx *Ud = reinterpret_cast<cplx *>(smem);                       // CH_NB * UD_LD
+    double *dinv = reinterpret_cast<double *>(Ud + CH_NB * UD_LD);   // CH_NB
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    cplx *A = R + (int64_t)f * n * n;
+    cplx *Z = P + (int64_t)f * n * D;
+    const int nblk = (n + CH_NB - 1) / CH_NB;
+
+    for (int J = 0; J < nblk; ++J) {
+        const int j0 = J * CH_NB, nb = min(CH_NB, n - j0);
+        __syncthreads();
+        chol_diag_block(A, n, j0, Ud, dinv);
+        __syncthreads();
+        // ---- row panel on the MFMA, one wave per tile of 16 columns
+        const int ntrail = n - j0 - nb;
+        const int npanel = (ntrail + 15) / 16 + (D + 15) / 16;
+        for (int ct = wave; ct < npanel; ct += 4) chol_panel_tile(A, Z, n, D, j0, nb, ct, Ud, dinv, lane);
+        __syncthreads();
+        // ---- trailing update on 32 x 32 tiles, round robin over the 4 waves
+        const int rs = j0 + nb;
+        const int nt = (n - rs + 31) / 32;
+        const int np = (D + 31) / 32;
+        const int ntiles = nt * (nt + 1) / 2 + nt * np;
+        for (int t = wave; t < ntiles; t += 4) {
+            UpdTile tl;
+            if (t < nt * (nt + 1) / 2) {
+                int a = 0, rem = t;
+                while (rem >= nt - a) {
+                    rem -= nt - a;
+                    ++a;
+                }
+                tl = {rs + 32 * a, rs + 32 * (a + rem), 0, 0};
+            } else {
+                const int u = t - nt * (nt + 1) / 2;
+                tl = {rs + 32 * (u / np), 32 * (u % np), 1, 0};
+            }
+            chol_update_tile<2, 2, true>(A, Z, n, D, j0, nb, tl, lane);
+        }
+    }
+    __syncthreads();
+    chol_backsolve_body(A, Z, n, D, Ud);     // S aliases the (now free) diagonal block
 }
 
 // ------------------------------------------------------------------ apply
@@ -811,8 +923,10 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     auto corr_fn = corr_ts == 2 ? (corr_3m ? wpe_corr_kernel<2, true> : wpe_corr_kernel<2, false>)
                                 : (corr_3m ? wpe_corr_kernel<3, true> : wpe_corr_kernel<3, false>);
     const size_t corr_lds = sizeof(cplx) * (size_t)(CORR_KT + c + padf) * D + sizeof(double) * CORR_KT;
-    const size_t panel_lds = sizeof(cplx) * CH_NB * CH_NB + sizeof(double) * CH_NB;
-    const size_t trsm_lds = sizeof(cplx) * (CH_NB * CH_NB + CH_NB * TRSM_COLS);
+    const size_t panel_lds = sizeof(cplx) * CH_NB * UD_LD + sizeof(double) * CH_NB;
+    const size_t fused_lds = panel_lds;
+    static_assert(BS_LD <= UD_LD, "S must fit in Ud");
+    const bool solve_fused = getenv("GSS_SOLVE_FUSED") != nullptr;
     const size_t apply_lds = sizeof(cplx) * (size_t)(AP_WG_FRAMES + c + 2) * D;
     GSS_REQUIRE(ctx, corr_lds <= 160 * 1024 && apply_lds <= 160 * 1024, GSS_ERR_UNSUPPORTED,
                 "wpe: taps=%d D=%d needs more LDS than a CU has", taps, D);
@@ -838,69 +952,76 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                                ctx->stream, Y, w, F, T, D, n, c, padf, tiles_dev, ntiles, R, P);
             GSS_LAUNCH_CHECK(ctx, "wpe_corr_kernel");
         }
-        const int nblk = (n + CH_NB - 1) / CH_NB;
-        for (int J = 0; J < nblk; ++J) {
-            const int j0 = J * CH_NB, nb = std::min(CH_NB, n - j0);
-            {
-                GSS_PROF(ctx, "wpe_chol_diag");
-                hipLaunchKernelGGL(chol_diag_kernel, dim3(F), dim3(256), panel_lds, ctx->stream, R, n,
-                                   j0);
-                GSS_LAUNCH_CHECK(ctx, "chol_diag_kernel");
-            }
-            {
-                GSS_PROF(ctx, "wpe_chol_trsm");
-                const int ncol = n - j0 - nb + D;
-                hipLaunchKernelGGL(chol_trsm_kernel, dim3((ncol + TRSM_COLS - 1) / TRSM_COLS, F),
-                                   dim3(256), trsm_lds, ctx->stream, R, P, n, D, j0);
-                GSS_LAUNCH_CHECK(ctx, "chol_trsm_kernel");
-            }
-            const int nupd = upd_count[J];
-            if (nupd > 0) {
-                GSS_PROF(ctx, "wpe_chol_update");
-                const dim3 g((nupd + 3) / 4, F), b(256);
-                const UpdTile *tl = upd_dev + upd_start[J];
-                switch (upd_variant & 7) {
-                    case 0:
-                        hipLaunchKernelGGL((chol_update_kernel<3, 3, true>), g, b, 0, ctx->stream,
-                                           R, P, n, D, j0, nb, tl, nupd);
-                        break;
-                    case 1:
-                        hipLaunchKernelGGL((chol_update_kernel<3, 3, false>), g, b, 0, ctx->stream,
-                                           R, P, n, D, j0, nb, tl, nupd);
-                        break;
-                    case 2:
-                        hipLaunchKernelGGL((chol_update_kernel<2, 3, true>), g, b, 0, ctx->stream,
-                                           R, P, n, D, j0, nb, tl, nupd);
-                        break;
-                    case 3:
-                        hipLaunchKernelGGL((chol_update_kernel<2, 2, true>), g, b, 0, ctx->stream,
-                                           R, P, n, D, j0, nb, tl, nupd);
-                        break;
-                    case 4:
-                        hipLaunchKernelGGL((chol_update_kernel<2, 2, false>), g, b, 0, ctx->stream,
-                                           R, P, n, D, j0, nb, tl, nupd);
-                        break;
-                    case 5:
-                        hipLaunchKernelGGL((chol_update_kernel<1, 2, true>), g, b, 0, ctx->stream,
-                                           R, P, n, D, j0, nb, tl, nupd);
-                        break;
-                    case 6:
-                        hipLaunchKernelGGL((chol_update_kernel<1, 1, true>), g, b, 0, ctx->stream,
-                                           R, P, n, D, j0, nb, tl, nupd);
-                        break;
-                    default:
-                        hipLaunchKernelGGL((chol_update_kernel<2, 4, true>), g, b, 0, ctx->stream,
-                                           R, P, n, D, j0, nb, tl, nupd);
-                        break;
+        if (solve_fused) {
+            GSS_PROF(ctx, "wpe_solve");
+            hipLaunchKernelGGL(wpe_solve_fused_kernel, dim3(F), dim3(256), fused_lds, ctx->stream,
+                               R, P, n, D);
+            GSS_LAUNCH_CHECK(ctx, "wpe_solve_fused_kernel");
+        } else {
+            const int nblk = (n + CH_NB - 1) / CH_NB;
+            for (int J = 0; J < nblk; ++J) {
+                const int j0 = J * CH_NB, nb = std::min(CH_NB, n - j0);
+                {
+                    GSS_PROF(ctx, "wpe_chol_diag");
+                    hipLaunchKernelGGL(chol_diag_kernel, dim3(F), dim3(256), panel_lds, ctx->stream, R, n,
+                                       j0);
+                    GSS_LAUNCH_CHECK(ctx, "chol_diag_kernel");
                 }
-                GSS_LAUNCH_CHECK(ctx, "chol_update_kernel");
+                {
+                    GSS_PROF(ctx, "wpe_chol_trsm");
+                    const int npanel = (n - j0 - nb + 15) / 16 + (D + 15) / 16;
+                    hipLaunchKernelGGL(chol_trsm_kernel, dim3((npanel + 3) / 4, F), dim3(256),
+                                       panel_lds, ctx->stream, R, P, n, D, j0);
+                    GSS_LAUNCH_CHECK(ctx, "chol_trsm_kernel");
+                }
+                const int nupd = upd_count[J];
+                if (nupd > 0) {
+                    GSS_PROF(ctx, "wpe_chol_update");
+                    const dim3 g((nupd + 3) / 4, F), b(256);
+                    const UpdTile *tl = upd_dev + upd_start[J];
+                    switch (upd_variant & 7) {
+                        case 0:
+                            hipLaunchKernelGGL((chol_update_kernel<3, 3, true>), g, b, 0, ctx->stream,
+                                               R, P, n, D, j0, nb, tl, nupd);
+                            break;
+                        case 1:
+                            hipLaunchKernelGGL((chol_update_kernel<3, 3, false>), g, b, 0, ctx->stream,
+                                               R, P, n, D, j0, nb, tl, nupd);
+                            break;
+                        case 2:
+                            hipLaunchKernelGGL((chol_update_kernel<2, 3, true>), g, b, 0, ctx->stream,
+                                               R, P, n, D, j0, nb, tl, nupd);
+                            break;
+                        case 3:
+                            hipLaunchKernelGGL((chol_update_kernel<2, 2, true>), g, b, 0, ctx->stream,
+                                               R, P, n, D, j0, nb, tl, nupd);
+                            break;
+                        case 4:
+                            hipLaunchKernelGGL((chol_update_kernel<2, 2, false>), g, b, 0, ctx->stream,
+                                               R, P, n, D, j0, nb, tl, nupd);
+                            break;
+                        case 5:
+                            hipLaunchKernelGGL((chol_update_kernel<1, 2, true>), g, b, 0, ctx->stream,
+                                               R, P, n, D, j0, nb, tl, nupd);
+                            break;
+                        case 6:
+                            hipLaunchKernelGGL((chol_update_kernel<1, 1, true>), g, b, 0, ctx->stream,
+                                               R, P, n, D, j0, nb, tl, nupd);
+                            break;
+                        default:
+                            hipLaunchKernelGGL((chol_update_kernel<2, 4, true>), g, b, 0, ctx->stream,
+                                               R, P, n, D, j0, nb, tl, nupd);
+                            break;
+                    }
+                    GSS_LAUNCH_CHECK(ctx, "chol_update_kernel");
+                }
             }
-        }
-        {
-            GSS_PROF(ctx, "wpe_backsolve");
-            hipLaunchKernelGGL(chol_backsolve_kernel, dim3(F), dim3(256), 0, ctx->stream, R, P, n,
-                               D);
-            GSS_LAUNCH_CHECK(ctx, "chol_backsolve_kernel");
+            {
+                GSS_PROF(ctx, "wpe_backsolve");
+                hipLaunchKernelGGL(chol_backsolve_kernel, dim3(F), dim3(256), 0, ctx->stream, R, P, n,
+                                   D);
+                GSS_LAUNCH_CHECK(ctx, "chol_backsolve_kernel");
+            }
         }
         {
             GSS_PROF(ctx, "wpe_apply");
@@ -912,6 +1033,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     }
     return GSS_OK;
 }
+
 
 int selftest_mfma_run(gss_ctx *ctx) {
     double *out = nullptr;
