@@ -56,30 +56,51 @@ class WPE:
         return Obs
 
 
+def default_database_path():
+    """The reference looks for ``<git root>/cache/chime5.json`` (core.py:20,98); here
+    ``$PB_CHIME5_JSON`` if set, else ``cache/chime5.json`` under the working directory."""
+    import os
+    return os.environ.get('PB_CHIME5_JSON', str(Path('cache') / 'chime5.json'))
+
+
 @dataclass
 class Activity:
-    """core.py:91-141.  The hot path only consumes
-    ``activity[session_id][array][speaker][start:stop] -> bool array``; anything
-    with that interface can be plugged in through ``store``.  ``type='path'``
-    reads the reference's per-session pickles.  Building the store from the CHiME
-    JSON (``type='annotation'``) is dataset preparation and out of scope."""
+    """core.py:91-141.  ``activity[session_id][array][speaker][start:stop] -> bool``.
+    ``type='annotation'`` derives the tracks from the utterance boundaries in the CHiME-5
+    JSON (one session cached, like the reference's ``lru_cache(1)``); ``type='path'``
+    reads the reference's per-session pickles; ``store`` plugs in a ready dict."""
     type: str = 'annotation'
     garbage_class: bool = False
     database_path: str = None
     path: str = None
     store: dict = None
 
+    def __post_init__(self):
+        self._db = None
+        self._cached = (None, None)
+
+    @property
+    def db(self):
+        if self._db is None:
+            from pb_chime5_amd.database.chime5.database import Chime5
+            self._db = Chime5(self.database_path or default_database_path())
+        return self._db
+
     def __getitem__(self, session_id):
         if self.store is not None:
             return self.store[session_id]
+        if self.type == 'annotation':
+            if self._cached[0] != session_id:
+                from pb_chime5_amd.activity import get_activity
+                self._cached = (session_id, get_activity(
+                    iterator=self.db.get_datasets(session_id), perspective='array',
+                    garbage_class=self.garbage_class, dtype=bool,
+                    use_ArrayIntervall=True)[session_id])
+            return self._cached[1]
         if self.type == 'path':
             import pickle
             with open(Path(self.path) / f'{session_id}.pkl', 'rb') as fd:
                 return pickle.load(fd)
-        if self.type == 'annotation':
-            raise NotImplementedError(
-                "Activity(type='annotation') needs the CHiME-5 JSON database, which "
-                'this build does not parse; pass Activity(store=...) or type="path".')
         raise ValueError(self.type)
 
 
@@ -200,17 +221,19 @@ class Enhancer:
         return default_context(self.device_id)
 
     # ------------------------------------------------------------------ sessions
+    @property
+    def db(self):
+        return self.activity.db
+
     def get_iterator(self, session_id):
-        """The reference builds this from its JSON database (core.py:323-331).
-        Here an ``iterator_factory(session_ids, context_samples)`` yielding the same
-        ``ex`` dicts has to be supplied (dataset plumbing is out of scope)."""
-        if self.iterator_factory is None:
-            raise RuntimeError(
-                'No example source: construct the Enhancer with '
-                'iterator_factory=callable(session_ids, context_samples) -> sequence '
-                'of example dicts (the CHiME JSON database layer is not part of '
-                'this build).')
-        return self.iterator_factory(session_id, self.context_samples)
+        """core.py:323-331.  ``iterator_factory(session_ids, context_samples)`` (an
+        addition) replaces the JSON database as the example source when given."""
+        if self.iterator_factory is not None:
+            return self.iterator_factory(session_id, self.context_samples)
+        return self.db.get_iterator_for_session(
+            session_id, audio_read=False, adjust_times=True,
+            drop_unknown_target_speaker=True, context_samples=self.context_samples,
+            equal_start_context=True)
 
     def enhance_session(self, session_ids, audio_dir, dataset_slice=False,
                         audio_dir_exist_ok=False):

@@ -7,6 +7,11 @@
   into one array (the reference's ``recursive_load_decorator``).
 * ``dump_audio(obj, path)`` peak-normalises to (2**15 - 1) / 2**15 and writes
   16-bit PCM at 16 kHz, like ``dump_audio(..., normalize=True, dtype=np.int16)``.
+  The float -> PCM16 step happens inside libsndfile in the reference; its result is
+  pinned by the doctest at io/audiowrite.py:49-52 ([1, 2, -4, 4] normalised reads back
+  as [0.24996948, 0.49996948, -0.99996948, 0.99996948], i.e. 8191.75 -> 8191 and
+  16383.5 -> 16383): scale to 32 bit, round, keep the upper 16 bits (floor), saturate
+  [UPSTREAM-RECALL libsndfile's clipping double -> short conversion].
 
 The reference uses ``soundfile`` (absent in this image); only RIFF/WAVE PCM16 --
 what CHiME-5/6 ships -- is handled here, with the standard-library ``wave``.
@@ -50,7 +55,8 @@ def dump_audio(obj, path, *, sample_rate=16000, normalize=True):
         correction = (2 ** 15 - 1) / (2 ** 15)
         obj = obj * (correction / np.amax(np.abs(obj)))
     if obj.dtype.kind == 'f':
-        pcm = np.clip(np.rint(obj * 2 ** 15), -2 ** 15, 2 ** 15 - 1).astype('<i2')
+        wide = np.rint(np.clip(obj.astype(np.float64), -1.0, 1.0) * 2.0 ** 31)
+        pcm = np.clip(np.floor(wide / 2 ** 16), -2 ** 15, 2 ** 15 - 1).astype('<i2')
     else:
         pcm = obj.astype('<i2')
     channels = 1 if pcm.ndim == 1 else pcm.shape[0]

@@ -1,0 +1,124 @@
+"""A small synthetic corpus in the CHiME-5 layout: per-array, per-channel PCM16 WAV
+files plus the example JSON the reference's ``create_json`` would write
+(/root/reference/pb_chime5/database/chime5/create_json.py:306-475: ``datasets`` keyed
+by session id, ``alias`` dev -> sessions; per example ``audio_path`` / ``start`` /
+``end`` / ``num_samples`` nested by 'observation' array and 'worn' microphone plus the
+'original' clock, ``speaker_id``, ``session_id``, ``transcription``,
+``reference_array``, ``location``).
+
+There is no CHiME-5 data in the build or test environment; this lets the whole
+session driver -- JSON database, annotation activity, context bookkeeping, WAV
+reading, enhancement, WAV writing -- run end to end.  Each array has its own clock:
+utterance boundaries are shifted by a per-array offset and a per-utterance jitter and
+differ slightly in duration, as in the real corpus, so that ``adjust_start_end`` and
+``AddContext(equal_start_context=True)`` have something to do.
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+
+from pb_chime5_amd import mapping
+from pb_chime5_amd.io import dump_audio
+from pb_chime5_amd.synthetic import SAMPLE_RATE, _rir, _source
+
+
+def _example_id(speaker_id, session_id, start, end, chime6=False):
+    a = str(int(start * 100 / SAMPLE_RATE)).zfill(7)
+    b = str(int(end * 100 / SAMPLE_RATE)).zfill(7)
+    if chime6:
+        return f'{speaker_id}_{session_id}-{a}-{b}'
+    return f'{speaker_id}_{session_id}_{a}-{b}'
+
+
+def write_chime5_corpus(root, session_id='S02', seconds=10.0, seed=11, utts_per_speaker=2,
+                        num_redacted=1, rir_taps=256, chime6=False):
+    """Writes ``root/audio/<dataset>/<session>_<array>.CH<m>.wav`` and
+    ``root/chime5.json``; returns the path of the JSON.  ``chime6=True`` writes the
+    CHiME-6 flavour instead (``root/chime6.json``): one synchronised clock, so start /
+    end / num_samples are plain integers (create_json.py:361-363,436-439)."""
+    from scipy.signal import fftconvolve
+    root = Path(root)
+    rng = np.random.default_rng(seed)
+    dataset = mapping.session_to_dataset[session_id]
+    speakers = mapping.session_to_speakers[session_id]
+    arrays = mapping.session_to_arrays[session_id]
+    n_total = int(seconds * SAMPLE_RATE)
+    audio_dir = root / 'audio' / dataset
+    audio_dir.mkdir(parents=True, exist_ok=True)
+
+    # ---- utterances on the 'original' clock
+    utterances = []
+    for spk in speakers:
+        for _ in range(utts_per_speaker):
+            length = int(rng.uniform(0.8, 2.0) * SAMPLE_RATE)
+            start = int(rng.integers(SAMPLE_RATE // 2, n_total - length - SAMPLE_RATE // 2))
+            utterances.append((spk, start, start + length, 'some words'))
+    for _ in range(num_redacted):
+        spk = speakers[int(rng.integers(len(speakers)))]
+        start = int(rng.integers(0, n_total - SAMPLE_RATE))
+        utterances.append((spk, start, start + SAMPLE_RATE // 2, '[redacted]'))
+    utterances.sort(key=lambda u: (u[1], u[0]))
+
+    # ---- audio: every speaker talks inside their (non redacted) utterances
+    channels = [(a, m) for a in arrays for m in range(1, 5)]
+    obs = np.zeros((len(channels), n_total))
+    for spk in speakers:
+        act = np.zeros(n_total, dtype=bool)
+        for s, a, b, words in utterances:
+            if s == spk and words != '[redacted]':
+                act[a:b] = True
+        src = _source(rng, n_total) * act
+        for d in range(len(channels)):
+            obs[d] += fftconvolve(src, _rir(rng, rir_taps))[:n_total]
+    obs += rng.standard_normal(obs.shape) * 1e-3
+    obs *= 0.05
+    for d, (a, m) in enumerate(channels):
+        dump_audio(obs[d], audio_dir / f'{session_id}_{a}.CH{m}.wav', normalize=False)
+
+    audio_path = {
+        'observation': {a: [str(audio_dir / f'{session_id}_{a}.CH{m}.wav') for m in range(1, 5)]
+                        for a in arrays},
+        'worn': {p: str(audio_dir / f'{session_id}_{p}.wav') for p in speakers},
+    }
+
+    # ---- per-clock boundaries
+    array_offset = {a: int(rng.integers(-300, 301)) for a in arrays}
+    worn_offset = {p: int(rng.integers(-100, 101)) for p in speakers}
+    examples = {}
+    for spk, start, end, words in utterances:
+        def clock(offset, jitter):
+            s = int(np.clip(start + offset + rng.integers(-jitter, jitter + 1), 0, n_total - 2))
+            e = int(np.clip(end + offset + rng.integers(-jitter, jitter + 1), s + 1, n_total))
+            return s, e
+        obs_times = {a: clock(array_offset[a], 40) for a in arrays}
+        worn_times = {p: clock(worn_offset[p], 10) for p in speakers}
+        start_d = {'observation': {a: t[0] for a, t in obs_times.items()},
+                   'worn': {p: t[0] for p, t in worn_times.items()}, 'original': start}
+        end_d = {'observation': {a: t[1] for a, t in obs_times.items()},
+                 'worn': {p: t[1] for p, t in worn_times.items()}, 'original': end}
+        num_d = {'observation': {a: t[1] - t[0] for a, t in obs_times.items()},
+                 'worn': {p: t[1] - t[0] for p, t in worn_times.items()},
+                 'original': end - start}
+        if chime6:
+            start_d, end_d, num_d = start, end, end - start
+        ex = {
+            'session_id': session_id,
+            'num_samples': num_d,
+            'audio_path': audio_path,
+            'notes': [],
+            'start': start_d,
+            'end': end_d,
+            'transcription': words,
+            'speaker_id': spk,
+            'gender': 'male',
+            'location': 'kitchen',
+            'reference_array': arrays[int(rng.integers(len(arrays)))],
+        }
+        examples[_example_id(spk, session_id, start, end, chime6)] = ex
+
+    database = {'datasets': {session_id: examples}, 'alias': {dataset: [session_id]}}
+    json_path = root / ('chime6.json' if chime6 else 'chime5.json')
+    with open(json_path, 'w') as fd:
+        json.dump(database, fd, indent=1, sort_keys=True)
+    return json_path

@@ -1,0 +1,298 @@
+"""CHiME-5 JSON front door: JSON database -> example
+iterator with context bookkeeping, annotation activity, WAV reading, session driver.
+
+Expected values come from tests/golden/chime5_session.{json,npz}, written by
+tests/golden/make_golden_session.py from the reference's real session code
+(database.py:83-131, activity.py:8-222, core.py:333-512, io/audioread.py) on the
+synthetic corpus that the tests regenerate here bit-identically."""
+import hashlib
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+GOLDEN = Path(__file__).parent / 'golden'
+
+
+def _load_fixture(name):
+    fx = json.loads((GOLDEN / f'{name}.json').read_text())
+    fx['name'] = name
+    return fx
+
+
+def _write_corpus(fx, root):
+    from pb_chime5_amd.synthetic_corpus import write_chime5_corpus
+    json_path = write_chime5_corpus(root, **fx['corpus'])
+    h = hashlib.sha256()
+    for p in sorted(root.rglob('*.wav')):
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    assert h.hexdigest() == fx['corpus_sha256'], 'synthetic corpus is not reproducible here'
+    return json_path
+
+
+@pytest.fixture(scope='module')
+def fixture():
+    return _load_fixture('chime5_session')
+
+
+@pytest.fixture(scope='module')
+def corpus(fixture, tmp_path_factory):
+    return _write_corpus(fixture, tmp_path_factory.mktemp('chime5_corpus'))
+
+
+@pytest.fixture(scope='module')
+def fixture6():
+    return _load_fixture('chime6_session')
+
+
+@pytest.fixture(scope='module')
+def corpus6(fixture6, tmp_path_factory):
+    return _write_corpus(fixture6, tmp_path_factory.mktemp('chime6_corpus'))
+
+
+def _enhancer(corpus, fixture, **kw):
+    if fixture['corpus'].get('chime6'):
+        from pb_chime5_amd.core_chime6 import get_enhancer
+    else:
+        from pb_chime5_amd.core import get_enhancer
+    return get_enhancer(database_path=str(corpus), **{**fixture['enhancer'], **kw})
+
+
+def test_iterator_bookkeeping_matches_reference(corpus, fixture):
+    enh = _enhancer(corpus, fixture)
+    it = enh.get_iterator(fixture['corpus']['session_id'])
+    assert len(it) == len(fixture['examples'])
+    for ex, want in zip(it, fixture['examples']):
+        assert ex['example_id'] == want['example_id']
+        assert ex['speaker_id'] == want['speaker_id']
+        assert ex['reference_array'] == want['reference_array']
+        for key in ('start', 'end', 'num_samples', 'start_orig', 'end_orig', 'num_samples_orig'):
+            assert ex[key] == want[key], (ex['example_id'], key)
+        assert ex['transcription'] != '[redacted]'
+    # the redacted utterance is in the database but not in the iterator
+    raw = enh.db.get_datasets(fixture['corpus']['session_id'])
+    assert len(raw) == len(it) + fixture['corpus']['num_redacted']
+
+
+def test_annotation_activity_matches_reference(corpus, fixture):
+    enh = _enhancer(corpus, fixture)
+    session_id = fixture['corpus']['session_id']
+    activity = enh.activity[session_id]
+    assert list(activity.keys()) == list(fixture['activity'].keys())
+    for array, tracks in fixture['activity'].items():
+        assert list(activity[array].keys()) == list(tracks.keys())
+        for spk, intervals in tracks.items():
+            got = [list(map(int, iv)) for iv in activity[array][spk].normalized_intervals]
+            assert got == intervals, (array, spk)
+    assert enh.activity[session_id] is activity          # one session is cached
+
+
+def test_chime6_iterator_and_activity_match_reference(corpus6, fixture6):
+    """core_chime6.py:322-331 (no time adjustment, plain context) and activity.py:225-403."""
+    enh = _enhancer(corpus6, fixture6)
+    it = enh.get_iterator('S02')
+    assert len(it) == len(fixture6['examples'])
+    for ex, want in zip(it, fixture6['examples']):
+        assert ex['example_id'] == want['example_id']
+        for key in ('start', 'end', 'num_samples', 'start_orig', 'end_orig', 'num_samples_orig'):
+            assert isinstance(ex[key], int) and ex[key] == want[key], (ex['example_id'], key)
+    activity = enh.activity['S02']
+    assert list(activity.keys()) == list(fixture6['activity'].keys())
+    for spk, intervals in fixture6['activity'].items():
+        assert [list(map(int, iv)) for iv in activity[spk].normalized_intervals] == intervals
+
+
+def test_get_activity_perspectives_and_dense(corpus, fixture):
+    from pb_chime5_amd.activity import get_activity
+    from pb_chime5_amd.database.chime5.database import Chime5
+    db = Chime5(corpus)
+    it = db.get_datasets('S02')
+    n_total = int(fixture['corpus']['seconds'] * 16000)
+    dense = get_activity(it, perspective='array', garbage_class=None, use_ArrayIntervall=False)
+    sparse = get_activity(it, perspective='array', garbage_class=True, use_ArrayIntervall=True)
+    assert 'Noise' not in dense['S02']['U01'] and 'Noise' in sparse['S02']['U01']
+    for array in dense['S02']:
+        for spk, track in dense['S02'][array].items():
+            assert track.dtype == bool and track.shape == (n_total,)
+            np.testing.assert_array_equal(track, sparse['S02'][array][spk][:])
+    worn = get_activity(it, perspective='global_worn', garbage_class=2, use_ArrayIntervall=True,
+                        num_samples={'S02_P': n_total})
+    assert list(worn['S02'].keys()) == ['P']
+    assert list(worn['S02']['P'].keys()) == ['P05', 'P06', 'P07', 'P08', 'Noise0', 'Noise1']
+    one = get_activity(it, perspective='U03', garbage_class=False, use_ArrayIntervall=True)
+    assert list(one['S02'].keys()) == ['U03']
+    assert not one['S02']['U03']['Noise'][:].any()
+    with pytest.raises(ValueError):
+        get_activity(it, perspective='array', garbage_class='yes')
+
+
+def test_example_list_operations():
+    from pb_chime5_amd.database import DictDatabase
+    db = DictDatabase({'datasets': {'A': {'a1': {'v': 1}, 'a2': {'v': 2}}, 'B': {'b1': {'v': 3}}},
+                       'alias': {'all': ['A', 'B']}})
+    it = db.get_datasets('all')
+    assert len(it) == 3 and it.keys() == ('a1', 'a2', 'b1')
+    assert it[0]['dataset'] == 'all' and db.get_datasets('A')[0]['dataset'] == 'A'
+
+    def bump(ex):
+        ex['v'] += 10
+        return ex
+    mapped = it.map(bump)
+    assert [ex['v'] for ex in mapped] == [11, 12, 13]
+    assert [ex['v'] for ex in mapped] == [11, 12, 13]          # examples are copied on access
+    assert [ex['v'] for ex in mapped.filter(lambda ex: ex['v'] > 11, lazy=False)] == [12, 13]
+    assert [ex['v'] for ex in mapped[1:]] == [12, 13]
+    assert [ex['v'] for ex in mapped[slice(0, None, 2)]] == [11, 13]
+    groups = mapped.groupby(lambda ex: ex['v'] % 2)
+    assert sorted(groups) == [0, 1] and len(groups[1]) == 2
+    assert mapped['b1']['v'] == 13
+    with pytest.raises(KeyError):
+        db.get_datasets('C')
+    with pytest.raises(RuntimeError):
+        DictDatabase({'datasets': {'E': {}}}).get_datasets('E')
+
+
+def test_example_id_map_fn():
+    from pb_chime5_amd.database.chime5.database import Chime5
+    # the two doctest vectors of database.py:59-81
+    assert Chime5.example_id_map_fn({'example_id': 'P05_S02_0004060-0004382', 'dataset': 'dev',
+                                     'location': 'kitchen'}) == 'P05_S02_KITCHEN.L-0004060-0004382'
+    assert Chime5.example_id_map_fn({'example_id': 'P09_S03_0005948-0006038', 'dataset': 'train',
+                                     'location': 'unknown'}) == 'P09_S03_NOLOCATION.L-0005948-0006038'
+
+
+def test_wav_known_answers(tmp_path):
+    """The doctest vectors of io/audiowrite.py:37-64 (float -> PCM16 -> float)."""
+    from pb_chime5_amd.io import dump_audio, load_audio
+    f = tmp_path / 'x.wav'
+    a = np.array([1, 2, -4, 4], dtype=np.int16)
+    dump_audio(a, f, normalize=False)
+    np.testing.assert_array_equal(load_audio(f) * 2 ** 15, [1., 2., -4., 4.])
+    dump_audio(a, f, normalize=True)
+    np.testing.assert_allclose(load_audio(f), [0.24996948, 0.49996948, -0.99996948, 0.99996948],
+                               atol=5e-9)
+    np.testing.assert_array_equal(load_audio(f) * 2 ** 15, [8191., 16383., -32767., 32767.])
+    data = np.arange(10) / 32
+    dump_audio(data, f, normalize=False)
+    np.testing.assert_array_equal(load_audio(f), data)
+    np.testing.assert_array_equal(load_audio(f, start=2, stop=5), data[2:5])
+    np.testing.assert_array_equal(load_audio([f, f]).shape, (2, 10))
+
+
+def test_loaded_observation_shape(corpus, fixture):
+    """Channel selection / alignment of enhance_example without touching the GPU."""
+    from pb_chime5_amd.io import load_audio
+    enh = _enhancer(corpus, fixture)
+    it = enh.get_iterator('S02')
+    gold = np.load(GOLDEN / 'chime5_session.npz')
+    for idx in fixture['enhanced']:
+        ex = it[idx]
+        arrays = [load_audio(ex['audio_path']['observation'][a], start=ex['start']['observation'][a],
+                             stop=ex['end']['observation'][a])
+                  for a in sorted(ex['audio_path']['observation'])]
+        n = min(v.shape[-1] for v in arrays)
+        assert (2 * len(arrays), n) == tuple(gold[f'obs_shape/{idx}'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('flavour', ['chime5', 'chime6'])
+def test_enhance_example_matches_reference(flavour, request):
+    from tests.conftest import rel_err
+    fixture = request.getfixturevalue('fixture' if flavour == 'chime5' else 'fixture6')
+    corpus = request.getfixturevalue('corpus' if flavour == 'chime5' else 'corpus6')
+    enh = _enhancer(corpus, fixture)
+    it = enh.get_iterator('S02')
+    gold = np.load(GOLDEN / f'{flavour}_session.npz')
+    for idx in fixture['enhanced']:
+        ex = it[idx]
+        x_hat = enh.enhance_example(ex, debug=True)
+        loc = enh.enhance_example_locals
+        assert loc['obs'].shape == tuple(gold[f'obs_shape/{idx}'])
+        act = np.array(list(loc['ex_array_activity'].values()))
+        assert [len(v) for v in loc['ex_array_activity'].values()] == list(gold[f'activity_len/{idx}'])
+        np.testing.assert_array_equal(np.packbits(act, axis=-1), gold[f'activity/{idx}'])
+        want = gold[f'x_hat/{idx}']
+        assert x_hat.shape == want.shape
+        n_orig = ex['num_samples_orig']
+        if flavour == 'chime5':
+            n_orig = n_orig['observation'][ex['reference_array']]
+        assert x_hat.shape[0] == n_orig
+        # BASELINE.json north_star tolerance: 1e-4 relative (observed ~4e-6: five EM
+        # iterations amplify the last-bit differences of the WPE solve)
+        assert rel_err(x_hat, want) < 1e-4
+
+
+@pytest.mark.gpu
+def test_enhance_session_writes_reference_layout(corpus, fixture, tmp_path):
+    """core.py:333-394: audio_dir/<dataset>/<example_id>.wav, peak normalised PCM16."""
+    from pb_chime5_amd.io import load_audio
+    enh = _enhancer(corpus, fixture)
+    audio_dir = tmp_path / 'audio'
+    enh.enhance_session('S02', audio_dir, dataset_slice=slice(0, None, 5))
+    written = sorted(p.relative_to(audio_dir).as_posix() for p in audio_dir.rglob('*.wav'))
+    ids = [ex['example_id'] for ex in fixture['examples']][0::5]
+    assert written == sorted(f'dev/{i}.wav' for i in ids)
+    assert (audio_dir / 'train').is_dir() and (audio_dir / 'eval').is_dir()
+    gold = np.load(GOLDEN / 'chime5_session.npz')
+    for idx in fixture['enhanced']:
+        if idx % 5:
+            continue
+        got = load_audio(audio_dir / 'dev' / f"{fixture['examples'][idx]['example_id']}.wav")
+        want = gold[f'x_hat/{idx}']
+        want = want * ((2 ** 15 - 1) / 2 ** 15 / np.max(np.abs(want)))
+        assert np.max(np.abs(got - want)) <= 2.0 / 2 ** 15       # floor to PCM16 + 1 LSB
+    with pytest.raises(FileExistsError):
+        enh.enhance_session('S02', audio_dir, dataset_slice=True)
+    enh.enhance_session('S02', audio_dir, dataset_slice=True, audio_dir_exist_ok=True)
+    assert len(list(audio_dir.rglob('*.wav'))) == 3       # examples 0, 5 and now 1
+
+
+# ---------------------------------------------------------------- command line
+def test_cli_config_parsing():
+    from pb_chime5_amd.scripts import run, kaldi_run, kaldi_run_rttm
+    cfg = run.main(['print_config', 'with', 'session_id=S02', 'wpe=False', 'wpe_tabs=4',
+                    'multiarray', 'bf=gev_ban', 'context_samples=16000'])
+    assert cfg['session_id'] == 'S02' and cfg['wpe'] is False and cfg['wpe_tabs'] == 4
+    assert cfg['multiarray'] is True and cfg['bf_drop_context'] is True and cfg['bf'] == 'gev_ban'
+    assert cfg['bss_iterations'] == 20 and cfg['chime6'] is False       # reference defaults
+    cfg = kaldi_run.main(['print_config', 'with', 'storage_dir=/x', 'job_id=3', 'number_of_jobs=8',
+                          'multiarray=outer_array_mics'])
+    assert (cfg['job_id'], cfg['number_of_jobs'], cfg['multiarray']) == (3, 8, 'outer_array_mics')
+    cfg = kaldi_run_rttm.main(['print_config', 'with', 'storage_dir=/x', 'database_rttm=a.rttm'])
+    assert cfg['activity_rttm'] == 'a.rttm' and cfg['multiarray'] == 'outer_array_mics'
+    with pytest.raises(SystemExit):
+        run.main(['print_config', 'with', 'no_such_key=1'])
+    with pytest.raises(SystemExit):
+        run.main(['frobnicate'])
+    assert run.get_session_ids('dev') == ['S02', 'S09']
+    assert run.get_session_ids(['eval', 'S03']) == ['S01', 'S03', 'S21']
+    assert len(run.get_session_ids('all')) == 20
+
+
+@pytest.mark.gpu
+def test_cli_kaldi_run_static_split(corpus, fixture, tmp_path):
+    """kaldi_run.py:59-90: job j of n writes examples j-1, j-1+n, ..."""
+    from pb_chime5_amd.scripts import kaldi_run
+    common = ['with', f'database_path={corpus}', 'session_id=S02', 'context_samples=8000',
+              'multiarray=first_array_mics', 'wpe=False', 'bss_iterations=2',
+              f'storage_dir={tmp_path}', 'number_of_jobs=3']
+    kaldi_run.main(common + ['job_id=2'])
+    ids = [ex['example_id'] for ex in fixture['examples']]
+    written = sorted(p.stem for p in (tmp_path / 'audio' / 'dev').glob('*.wav'))
+    assert written == sorted(ids[1::3])
+    assert (tmp_path / 'sacred' / '1' / 'config.json').exists()
+    with pytest.raises(AssertionError):
+        kaldi_run.main(common + ['job_id=4'])
+
+
+@pytest.mark.gpu
+def test_cli_run_test_run(corpus, tmp_path):
+    """run.py test_run: the first two examples into <file_storage>/<id>/audio."""
+    from pb_chime5_amd.scripts import run
+    run_dir = run.main(['test_run', 'with', f'database_path={corpus}', 'session_id=S02',
+                        'context_samples=8000', 'wpe=False', 'bss_iterations=2',
+                        'reference_array=U02', '-F', str(tmp_path / 'store')])
+    assert run_dir == tmp_path / 'store' / '1'
+    assert len(list((run_dir / 'audio' / 'dev').glob('*.wav'))) == 2
