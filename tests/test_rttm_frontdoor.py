@@ -15,7 +15,7 @@ SPEAKER S09_U06 1 0.00 0.10 <NA> <NA> P25 <NA>
 
 
 def _make_chime6_dir(tmp_path, num_samples=52000, arrays=('U01', 'U02', 'U03')):
-    from pb_chime5_amd.io import dump_audio
+    from pb_chime5_amd.io import dump_audio, load_audio
     rng = np.random.default_rng(7)
     root = tmp_path / 'CHiME6'
     audio = {}
@@ -27,7 +27,7 @@ def _make_chime6_dir(tmp_path, num_samples=52000, arrays=('U01', 'U02', 'U03')):
             x = rng.standard_normal(n) * 0.05
             path = root / 'audio' / 'dev' / f'S02_{a}.CH{ch}.wav'
             dump_audio(x, path, normalize=False)
-            audio[path.name] = np.rint(x * 2 ** 15).clip(-2 ** 15, 2 ** 15 - 1) / 2 ** 15
+            audio[path.name] = load_audio(path)
     rttm = tmp_path / 'dev_rttm'
     rttm.write_text(RTTM)
     return root, rttm, audio
