@@ -569,10 +569,16 @@ __device__ inline void store_covariance(const cplx (&vals)[COV_SLOTS], int D, do
 // evaluates q = y^H V diag(1/lambda) V^H y and ln det = sum ln lambda.  A per-class
 // scale of lambda cancels between -D ln q and -ln det, and rescales the next
 // covariance by a constant that the next normalisation removes again.  So whenever
-// NO eigenvalue is floored -- lambda_min > 1e-10 lambda_max, certified here by a
-// successful Cholesky factorisation of B - 1e-10 tr(B) I (tr B >= lambda_max) --
-// B^-1 and ln det B from a Cholesky factorisation give the same posteriors.
-// Matrices that fail the certificate are flagged for em_eigh_kernel.
+// NO eigenvalue is floored -- lambda_min > 1e-10 lambda_max -- B^-1 and ln det B from a
+// Cholesky factorisation give the same posteriors.  The certificate comes out of the
+// quantities computed anyway:  lambda_min >= 1 / ||B^-1||_F  and  lambda_max <= ||B||_F,
+// so  ||B||_F ||B^-1||_F < 0.5e10  proves that nothing would be floored (conservative
+// by at most a factor D).  Matrices that fail it, or whose factorisation breaks down,
+// are flagged for em_eigh_kernel, which overwrites their rows.
+//
+// Factor and inverse come from ONE register-resident sweep (chol_inverse_sweep,
+// 8 x 8 lane grid, NR x NR entries per lane, D <= 8 NR).
+template <int NR>
 __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp,
                                                      const double *__restrict__ Sg, int nch,
                                                      int sg_nch, int D,
@@ -582,9 +588,10 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
                                                      double *__restrict__ pi,
                                                      int *__restrict__ need_eigh) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ld = D + (D & 1);
+    constexpr int ld = 8 * NR + 1;
     const int NE = tri_count(D);
-    cplx *A = reinterpret_cast<cplx *>(smem);   // D * ld
+    cplx *A = reinterpret_cast<cplx *>(smem);                  // D * ld
+    double *dinv = reinterpret_cast<double *>(A + D * ld);     // D
     const int k = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
 
     double sg = 0.0;
@@ -592,29 +599,53 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
     const double den = fmax(sg, GSS_TINY);
     if (lane == 0) pi[f * K + k] = sg / (double)T;
 
-    // certificate: B - floor * tr(B) * I positive definite
     cplx vals[COV_SLOTS];
     const double tr = reduce_covariance(Bp, nch, D, K, k, f, den, vals, lane);
     bool fast = !force_eigh && tr > 0.0 && isfinite(tr);
-    if (fast) {
-        store_covariance(vals, D, eig_floor * tr, false, A, ld, lane);
-        __syncthreads();
-        fast = cholesky_lower_wave(A, D, ld, lane);
+    if (!fast) {
+        if (lane == 0) need_eigh[f * K + k] = 1;
+        return;
     }
-    if (fast) {
-        __syncthreads();
-        store_covariance(vals, D, 0.0, false, A, ld, lane);
-        __syncthreads();
-        fast = cholesky_lower_wave(A, D, ld, lane);   // B itself is PD a fortiori
+    double nb2 = 0.0;   // ||B||_F^2 from the packed upper triangle
+#pragma unroll
+    for (int s = 0; s < COV_SLOTS; ++s) {
+        const int e = lane + 64 * s;
+        if (e < NE) {
+            int d1, d2;
+            tri_unpack(e, D, d1, d2);
+            nb2 += (d1 == d2 ? 1.0 : 2.0) * (vals[s].x * vals[s].x + vals[s].y * vals[s].y);
+        }
     }
-    if (lane == 0) need_eigh[f * K + k] = fast ? 0 : 1;
-    if (!fast) return;
-    double ldv = 0.0;
-    for (int i = lane; i < D; i += 64) ldv += 2.0 * log(A[i * ld + i].x);
-    ldv = wave_sum(ldv);
+    nb2 = wave_sum(nb2);
+    store_covariance(vals, D, 0.0, true, A, ld, lane);
     __syncthreads();
-    invert_lower_wave(A, D, ld, lane);
-    // B^-1 = Linv^H Linv :  (d1,d2) = sum_{j >= d2} conj(Linv[j][d1]) Linv[j][d2]
+    const int tx = lane & 7, ty = lane >> 3;
+    cplx reg[NR][NR];
+#pragma unroll
+    for (int a = 0; a < NR; ++a)
+#pragma unroll
+        for (int b = 0; b < NR; ++b) {
+            const int i = ty + 8 * a, kk = tx + 8 * b;
+            reg[a][b] = (kk >= i && kk < D) ? A[i * ld + kk] : c_make(0.0, 0.0);
+        }
+    __syncthreads();
+    fast = chol_inverse_sweep<8, NR>(reg, D, A, ld, dinv, tx, ty);
+    if (!fast) {
+        if (lane == 0) need_eigh[f * K + k] = 1;
+        return;
+    }
+    double ldv = 0.0;   // ln det B = 2 sum ln U_ii
+    for (int i = lane; i < D; i += 64) ldv -= 2.0 * log(dinv[i]);
+    ldv = wave_sum(ldv);
+    // W = U^-H: scale the unscaled rows of the sweep (strictly lower part), set the diagonal
+    for (int idx = lane; idx < D * D; idx += 64) {
+        const int i = idx / D, kk = idx - i * D;
+        if (kk < i) A[i * ld + kk] = c_scale(A[i * ld + kk], dinv[i]);
+        else if (kk == i) A[i * ld + i] = c_make(dinv[i], 0.0);
+    }
+    __syncthreads();
+    // B^-1 = W^H W :  (d1,d2) = sum_{j >= d2} conj(W[j][d1]) W[j][d2]
+    double ni2 = 0.0;
     for (int e = lane; e < NE; e += 64) {
         int d1, d2;
         tri_unpack(e, D, d1, d2);
@@ -622,13 +653,21 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
         for (int j = d2; j < D; ++j) c_cfma(v, A[j * ld + d1], A[j * ld + d2]);
         if (d1 == d2) {
             v.y = 0.0;
+            ni2 += v.x * v.x;
         } else {
+            ni2 += 2.0 * (v.x * v.x + v.y * v.y);
             v.x *= 2.0;
             v.y *= 2.0;
         }
         Mq[((int64_t)f * NE + e) * K + k] = v;
     }
-    if (lane == 0) logdet[f * K + k] = ldv;
+    ni2 = wave_sum(ni2);
+    const double bound = 0.5 / eig_floor;
+    fast = isfinite(ni2) && nb2 * ni2 < bound * bound;
+    if (lane == 0) {
+        need_eigh[f * K + k] = fast ? 0 : 1;
+        logdet[f * K + k] = ldv;
+    }
 }
 
 // Eigendecomposition path for the flagged matrices: eigenvalues / max, floor, then
@@ -896,7 +935,6 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     GSS_REQUIRE(ctx, em_estep_lds(D, K) <= 160 * 1024 && wcov_lds_layout(D, K).total <= 160 * 1024,
                 GSS_ERR_UNSUPPORTED, "cacgmm: D=%d K=%d LDS", D, K);
     const int m = D + (D & 1);
-    const size_t chol_lds = (sizeof(cplx) * (size_t)D * m + 15) / 16 * 16;
     const size_t eigh_lds = (sizeof(cplx) * 2 * m * m + sizeof(double) * m + 15) / 16 * 16;
     const int force_eigh = getenv("GSS_FORCE_EIGH") != nullptr;
     int *need_eigh = arena_alloc_t<int>(ctx, (size_t)F * K);
@@ -906,9 +944,12 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     auto eig = [&]() -> int {
         {
             GSS_PROF(ctx, "em_chol");
-            hipLaunchKernelGGL(em_chol_kernel, dim3(K, F), dim3(64), chol_lds, ctx->stream, a.Bp,
-                               a.Sg, a.nch, sg_nch, D, K, T, 1e-10, force_eigh, Mq, logdet, pi,
-                               need_eigh);
+            const int nr = (D + 7) / 8;
+            const size_t lds = sizeof(cplx) * (size_t)D * (8 * nr + 1) + sizeof(double) * D;
+            auto kern = nr <= 1 ? em_chol_kernel<1> : nr == 2 ? em_chol_kernel<2>
+                        : nr == 3 ? em_chol_kernel<3> : em_chol_kernel<4>;
+            hipLaunchKernelGGL(kern, dim3(K, F), dim3(64), lds, ctx->stream, a.Bp, a.Sg, a.nch,
+                               sg_nch, D, K, T, 1e-10, force_eigh, Mq, logdet, pi, need_eigh);
             GSS_LAUNCH_CHECK(ctx, "em_chol_kernel");
         }
         {

@@ -55,3 +55,84 @@ __device__ inline void invert_lower_wave(cplx *A, int n, int ld, int lane) {
     }
 }
 
+
+// Cholesky factor AND its inverse in one register-resident sweep (used on the WPE
+// diagonal blocks by 256 threads, G = 16, and on the CACGMM class covariances by one
+// wave, G = 8).  The n x n Hermitian matrix (n <= G * NR) lives in registers, NR x NR
+// entries per thread: entry (a, b) of thread (ty, tx) is (i, k) = (ty + G a, tx + G b).
+// On entry reg holds the upper triangle (k >= i) of the matrix and zeros elsewhere.
+// One right-looking pass of n steps builds U (A = U^H U, upper part) and
+// W = U^-H (strictly lower part) together: per step the owners of row j publish it
+// through LDS, ONE barrier, then every thread reads the pivot, its NR row and NR
+// column factors and updates its entries.  The dependent chain is n x (LDS round trip
+// + rsqrt + NR^2 complex FMAs) instead of two LDS-bound triangular sweeps.
+// On exit the LDS array M (leading dimension ld) holds the UNSCALED rows -- row j is
+// U[j][k] / dinv[j] for k > j, W[j][k] / dinv[j] for k < j, the pivot a_jj at k = j --
+// and dinv[j] = 1 / U[j][j] (0 where the pivot was not positive and finite); callers
+// scale when they consume.  Returns false (uniformly) if any pivot failed.
+template <int G, int NR>
+__device__ __forceinline__ bool chol_inverse_sweep(cplx (&reg)[NR][NR], int n, cplx *M, int ld,
+                                          double *dinv, int tx, int ty) {
+    bool ok = true;
+    for (int j = 0; j < n; ++j) {
+        // row j = block row j / G of the owners (ty == j % G); select it without
+        // indexing the register array dynamically
+        cplx pub[NR];
+#pragma unroll
+        for (int b = 0; b < NR; ++b) pub[b] = reg[0][b];
+#pragma unroll
+        for (int a = 1; a < NR; ++a)
+            if (j >= G * a) {
+#pragma unroll
+                for (int b = 0; b < NR; ++b) pub[b] = reg[a][b];
+            }
+        if (ty == j % G) {
+#pragma unroll
+            for (int b = 0; b < NR; ++b) M[j * ld + tx + G * b] = pub[b];
+        }
+        __syncthreads();
+        // all LDS reads of the step are issued together, unconditionally
+        const double ajj = M[j * ld + j].x;
+        cplx ru[NR], rv[NR];
+#pragma unroll
+        for (int a = 0; a < NR; ++a) ru[a] = M[j * ld + ty + G * a];
+#pragma unroll
+        for (int b = 0; b < NR; ++b) rv[b] = M[j * ld + tx + G * b];
+        double di = 0.0;
+        if (ajj > 0.0 && isfinite(ajj)) di = rsqrt(ajj);
+        else ok = false;
+        if (tx == 0 && ty == 0) dinv[j] = di;
+        cplx u[NR], v[NR];
+#pragma unroll
+        for (int a = 0; a < NR; ++a) {
+            // conj(U[j][i]) for the rows below the pivot, 0 elsewhere
+            const double s = ty + G * a > j ? di : 0.0;
+            u[a] = c_make(ru[a].x * s, -ru[a].y * s);
+        }
+#pragma unroll
+        for (int b = 0; b < NR; ++b) {
+            // k > j: U[j][k];  k < j: W[j][k];  k == j: W[j][j] = 1 / U[j][j]
+            v[b] = tx + G * b == j ? c_make(di, 0.0) : c_scale(rv[b], di);
+        }
+        // entry (a, b) is an upper (U) entry when b > a, a W entry when b < a, and on
+        // a == b it depends on the thread; W entries only take columns k <= j
+        cplx vw[NR], vd[NR];
+#pragma unroll
+        for (int b = 0; b < NR; ++b) {
+            vw[b] = tx + G * b <= j ? v[b] : c_make(0.0, 0.0);
+            vd[b] = tx >= ty ? v[b] : vw[b];
+        }
+#pragma unroll
+        for (int a = 0; a < NR; ++a)
+#pragma unroll
+            for (int b = 0; b < NR; ++b) {
+                const cplx vv = b > a ? v[b] : (b < a ? vw[b] : vd[b]);
+                reg[a][b].x = fma(-u[a].x, vv.x, reg[a][b].x);
+                reg[a][b].x = fma(u[a].y, vv.y, reg[a][b].x);
+                reg[a][b].y = fma(-u[a].x, vv.y, reg[a][b].y);
+                reg[a][b].y = fma(-u[a].y, vv.x, reg[a][b].y);
+            }
+    }
+    __syncthreads();
+    return ok;
+}

@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "gss_internal.h"
+#include "dense_wave.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -242,12 +243,8 @@ constexpr int UD_LD = CH_NB + 1;   // LDS leading dimension of the diagonal bloc
 
 // Factor the diagonal block at j0 of one frequency's matrix A (256 threads):
 // Ud <- U_JJ (upper) and W = U_JJ^-H (strictly lower), dinv <- 1 / diag(U_JJ); both are
-// also written back to A.  The block lives in REGISTERS, 3 x 3 entries per thread
-// (entry (i, k): i = ty + 16 a, k = tx + 16 b; upper part = trailing matrix / U, strictly
-// lower part = W under construction), and one sweep of nb right-looking steps builds U
-// and W together: per step the owners of row j publish it through LDS, ONE barrier,
-// then every thread reads the pivot, its 3 row and 3 column factors and updates its 9
-// entries.  The dependent chain is nb x (LDS round trip + rsqrt + 9 complex FMAs).
+// also written back to A.  The block lives in registers, 3 x 3 entries per thread, and
+// one pass of nb steps builds U and W together (chol_inverse_sweep in dense_wave.h).
 __device__ inline void chol_diag_block(cplx *A, int n, int j0, cplx *Ud, double *dinv) {
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int nb = min(CH_NB, n - j0);
@@ -259,58 +256,7 @@ __device__ inline void chol_diag_block(cplx *A, int n, int j0, cplx *Ud, double 
             const int i = ty + 16 * a, k = tx + 16 * b;
             reg[a][b] = (k >= i && k < nb) ? A[(int64_t)(j0 + i) * n + j0 + k] : c_make(0.0, 0.0);
         }
-    for (int j = 0; j < nb; ++j) {
-        if (ty == (j & 15)) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-                if (a == (j >> 4)) {
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) Ud[j * UD_LD + tx + 16 * b] = reg[a][b];
-                }
-        }
-        __syncthreads();
-        // all LDS reads of the step are issued together, unconditionally
-        const double ajj = Ud[j * UD_LD + j].x;
-        cplx ru[3], rv[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) ru[a] = Ud[j * UD_LD + ty + 16 * a];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) rv[b] = Ud[j * UD_LD + tx + 16 * b];
-        double di = 0.0;
-        if (ajj > 0.0 && isfinite(ajj)) di = rsqrt(ajj);
-        if (tid == 0) dinv[j] = di;
-        cplx u[3], v[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            // conj(U[j][i]) for the rows below the pivot, 0 elsewhere
-            const double s = ty + 16 * a > j ? di : 0.0;
-            u[a] = c_make(ru[a].x * s, -ru[a].y * s);
-        }
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            // k > j: U[j][k];  k < j: W[j][k];  k == j: W[j][j] = 1 / U[j][j]
-            v[b] = tx + 16 * b == j ? c_make(di, 0.0) : c_scale(rv[b], di);
-        }
-        // entry (a, b) is an upper (U) entry when b > a, a W entry when b < a, and on
-        // a == b it depends on the thread; W entries only take columns k <= j
-        cplx vw[3], vd[3];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            vw[b] = tx + 16 * b <= j ? v[b] : c_make(0.0, 0.0);
-            vd[b] = tx >= ty ? v[b] : vw[b];
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const cplx vv = b > a ? v[b] : (b < a ? vw[b] : vd[b]);
-                reg[a][b].x = fma(-u[a].x, vv.x, reg[a][b].x);
-                reg[a][b].x = fma(u[a].y, vv.y, reg[a][b].x);
-                reg[a][b].y = fma(-u[a].x, vv.y, reg[a][b].y);
-                reg[a][b].y = fma(-u[a].y, vv.x, reg[a][b].y);
-            }
-    }
-    __syncthreads();
+    chol_inverse_sweep<16, 3>(reg, nb, Ud, UD_LD, dinv, tx, ty);
     // rows were published unscaled: scale them, fix the diagonal, clear the padding
     for (int idx = tid; idx < CH_NB * CH_NB; idx += blockDim.x) {
         const int i = idx / CH_NB, k = idx - i * CH_NB;
