@@ -19,8 +19,13 @@ LIB_DIR = PKG / 'lib'
 LIB_PATH = LIB_DIR / 'libgss_hip.so'
 SOURCES = ['gss_api.hip', 'stft.hip', 'wpe.hip', 'cacgmm.hip', 'mvdr.hip']
 HEADERS = ['gss_internal.h', 'jacobi.h', 'dense_wave.h', '../../include/gss_hip.h']
+# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs.  Without it the compiler
+# puts loop-carried accumulators in VGPRs but the MFMA destination in AGPRs and copies
+# every accumulator there and back (plus a wait for the MFMA result) in each k step of
+# the apply / trailing-update loops.  All kernels here need < 256 VGPRs.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
-         '-ffp-contract=on', '-fno-fast-math', '-Wall', '-Wno-unused-function']
+         '-ffp-contract=on', '-fno-fast-math', '-Wall', '-Wno-unused-function',
+         '-mllvm', '-amdgpu-mfma-vgpr-form=1']
 
 
 def _hipcc():

@@ -657,106 +657,122 @@ __global__ __launch_bounds__(256, 3) void wpe_solve_fused_kernel(cplx *__restric
 
 // ------------------------------------------------------------------ apply
 // X[t][d] = Y[t][d] - sum_r conj(G[r][d]) Yflat[(t - c) D + r]
-// As a GEMM per frequency: out(frames x channels) = U^T conj(G), K = n = taps * D,
-// on the f64 MFMA.  A[i = frame][k = r] comes from the LDS copy of the sliding
-// window, B[k = r][j = d] straight from G in global memory (L2 resident, shared
-// by all workgroups of a frequency), double-buffered in registers.
-// grid (ceil(T / 128), F), block 256: each wave owns 32 frames x 32 channel slots.
-constexpr int AP_WAVE_FRAMES = 32;
-constexpr int AP_WG_FRAMES = 4 * AP_WAVE_FRAMES;
-
+// As a GEMM per frequency: out(frames x channels) = U conj(G), K = n = taps * D, on the
+// f64 MFMA.  A[i = frame][k = r] comes from the LDS copy of the frames the workgroup
+// touches -- stored with an odd frame stride DP so that the 16 frames of a fragment
+// hit 16 different bank groups; (frame fl, r) lives at (fl + r / D) * DP + r % D --
+// B[k = r][j = d] straight from G in global memory (L2 / L1 resident, shared by all
+// waves of a frequency), double-buffered in registers.
+// grid (ceil(T / (64 TA)), F), block 256: each wave owns 16 TA frames x 16 NB channel
+// slots.  NB (channel tiles) is a template parameter: a run-time tile count inside the
+// k loop makes the compiler shuttle the accumulators between VGPRs and AGPRs around
+// every MFMA and wait for each result.
+template <int TA, int NB>
 __global__ __launch_bounds__(256) void wpe_apply_kernel(const cplx *__restrict__ Y,
                                                         const cplx *__restrict__ G, int F,
                                                         int64_t T, int D, int n, int c,
                                                         cplx *__restrict__ X) {
+    constexpr int WAVE_FRAMES = 16 * TA, WG_FRAMES = 4 * WAVE_FRAMES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cplx *S = reinterpret_cast<cplx *>(smem);   // (AP_WG_FRAMES + c + 2) * D
+    cplx *S = reinterpret_cast<cplx *>(smem);   // (WG_FRAMES + c + 2) * DP
+    const int DP = D | 1;
     int f, chunk;
-    if (!xcd_group_map((int)((T + AP_WG_FRAMES - 1) / AP_WG_FRAMES), F, f, chunk)) return;
-    const int64_t t0 = (int64_t)chunk * AP_WG_FRAMES;
+    if (!xcd_group_map((int)((T + WG_FRAMES - 1) / WG_FRAMES), F, f, chunk)) return;
+    const int64_t t0 = (int64_t)chunk * WG_FRAMES;
     const cplx *Yf = Y + (int64_t)f * T * D;
     const cplx *Gf = G + (int64_t)f * n * D;
-    const int frames_lds = AP_WG_FRAMES + c + 2;
+    const int frames_lds = WG_FRAMES + c + 2;
     const int64_t fr0 = t0 - c;
     for (int idx = threadIdx.x; idx < frames_lds * D; idx += blockDim.x) {
-        const int64_t fr = fr0 + idx / D;
+        const int fl = idx / D, d = idx - fl * D;
+        const int64_t fr = fr0 + fl;
         cplx v = c_make(0.0, 0.0);
         if (fr >= 0 && fr < T) v = Yf[fr0 * D + idx];
-        S[idx] = v;
+        S[fl * DP + d] = v;
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
-    const int wf0 = wave * AP_WAVE_FRAMES;       // first frame of this wave, tile relative
-    const int nct = (D + 15) / 16;                // channel tiles (<= 2)
-
-    v4d acc_re[2][2], acc_im[2][2];
+    const int wf0 = wave * WAVE_FRAMES;          // first frame of this wave, tile relative
+    v4d acc_re[TA][NB], acc_im[TA][NB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NB; ++b) {
             acc_re[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
             acc_im[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
         }
-    auto load_b = [&](int ks, cplx (&g)[2]) {
+    // loads are unconditional (clamped address, zero selected afterwards) and the k loop
+    // has no branch: with control flow inside it the compiler keeps the accumulators in
+    // VGPRs and copies them to AGPRs and back around every group of MFMAs
+    auto load_b = [&](int ks, cplx (&g)[NB]) {
         const int r = 4 * ks + lk;
+        const int rc = min(r, n - 1);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NB; ++b) {
             const int d = 16 * b + li;
-            g[b] = (r < n && d < D) ? Gf[(int64_t)r * D + d] : c_make(0.0, 0.0);
+            const cplx v = Gf[(int64_t)rc * D + min(d, D - 1)];
+            const bool ok = r < n && d < D;
+            g[b] = c_make(ok ? v.x : 0.0, ok ? v.y : 0.0);
         }
     };
     const int ksteps = (n + 3) / 4;
-    cplx g_cur[2], g_nxt[2];
+    cplx g_cur[NB], g_nxt[NB];
     load_b(0, g_cur);
+    // r = 4 ks + lk = rq D + rm, advanced without dividing
+    int rq = lk / D, rm = lk - rq * D;
     for (int ks = 0; ks < ksteps; ++ks) {
-        if (ks + 1 < ksteps) load_b(ks + 1, g_nxt);
-        const int r = 4 * ks + lk;
-        double ur[2], ui[2], gr[2], gi[2], ngi[2];
+        load_b(min(ks + 1, ksteps - 1), g_nxt);
+        double ur[TA], ui[TA], gr[NB], gi[NB], ngi[NB];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const cplx u = S[(wf0 + 16 * a + li) * D + r];
+        for (int a = 0; a < TA; ++a) {
+            const cplx u = S[(wf0 + 16 * a + li + rq) * DP + rm];
             ur[a] = u.x;
             ui[a] = u.y;
         }
+        rm += 4;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int w = 0; w < 4; ++w) {   // D >= 1: at most 4 wraps, branch free
+            const bool wrap = rm >= D;
+            rm -= wrap ? D : 0;
+            rq += wrap ? 1 : 0;
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
             gr[b] = g_cur[b].x;
             gi[b] = g_cur[b].y;
             ngi[b] = -g_cur[b].y;
         }
         // u * conj(g)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < TA; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                if (b >= nct) continue;
+            for (int b = 0; b < NB; ++b) {
                 acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[a], gr[b], acc_re[a][b], 0, 0, 0);
                 acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui[a], gr[b], acc_im[a][b], 0, 0, 0);
             }
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < TA; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                if (b >= nct) continue;
+            for (int b = 0; b < NB; ++b) {
                 acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui[a], gi[b], acc_re[a][b], 0, 0, 0);
                 acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[a], ngi[b], acc_im[a][b], 0, 0, 0);
             }
-        g_cur[0] = g_nxt[0];
-        g_cur[1] = g_nxt[1];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) g_cur[b] = g_nxt[b];
     }
     // C/D fragment: col = li (channel), row = lk + 4 * reg (frame)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int fl = wf0 + 16 * a + lk + 4 * reg;
                 const int d = 16 * b + li;
                 const int64_t t = t0 + fl;
                 if (d < D && t < T) {
-                    const cplx y = S[(fl + c) * D + d];
+                    const cplx y = S[(fl + c) * DP + d];
                     X[((int64_t)f * T + t) * D + d] =
                         c_make(y.x - acc_re[a][b][reg], y.y - acc_im[a][b][reg]);
                 }
@@ -873,11 +889,15 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     const size_t fused_lds = panel_lds;
     static_assert(BS_LD <= UD_LD, "S must fit in Ud");
     const bool solve_fused = getenv("GSS_SOLVE_FUSED") != nullptr;
-    const size_t apply_lds = sizeof(cplx) * (size_t)(AP_WG_FRAMES + c + 2) * D;
+    static const int apply_ta = getenv("GSS_APPLY_TA") ? atoi(getenv("GSS_APPLY_TA")) : 2;
+    const int apply_frames = apply_ta == 2 ? 128 : 64;
+    auto apply_fn = D <= 16 ? (apply_ta == 2 ? wpe_apply_kernel<2, 1> : wpe_apply_kernel<1, 1>)
+                            : (apply_ta == 2 ? wpe_apply_kernel<2, 2> : wpe_apply_kernel<1, 2>);
+    const size_t apply_lds = sizeof(cplx) * (size_t)(apply_frames + c + 2) * (D | 1);
     GSS_REQUIRE(ctx, corr_lds <= 160 * 1024 && apply_lds <= 160 * 1024, GSS_ERR_UNSUPPORTED,
                 "wpe: taps=%d D=%d needs more LDS than a CU has", taps, D);
     if (apply_lds > 64 * 1024)
-        GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(wpe_apply_kernel),
+        GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(apply_fn),
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)apply_lds));
     if (corr_lds > 64 * 1024)
@@ -971,8 +991,8 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         }
         {
             GSS_PROF(ctx, "wpe_apply");
-            hipLaunchKernelGGL(wpe_apply_kernel,
-                               dim3(xcd_grid((int)((T + AP_WG_FRAMES - 1) / AP_WG_FRAMES), F)),
+            hipLaunchKernelGGL(apply_fn,
+                               dim3(xcd_grid((int)((T + apply_frames - 1) / apply_frames), F)),
                                dim3(256), apply_lds, ctx->stream, Y, P, F, T, D, n, c, X);
             GSS_LAUNCH_CHECK(ctx, "wpe_apply_kernel");
         }
