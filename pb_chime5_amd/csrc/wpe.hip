@@ -881,7 +881,9 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     UpdTile *upd_dev = reinterpret_cast<UpdTile *>(tiles_dev + 1024);
 
     const int padf = corr_padf(D, 16 * corr_ts);
-    const bool corr_3m = getenv("GSS_CORR_3M") != nullptr;
+    // 3 real MFMAs per complex product (t1 = ar br, t2 = ai bi, t3 = (ar + ai)(br - bi));
+    // GSS_CORR_4M=1 selects the 4-product form
+    const bool corr_3m = getenv("GSS_CORR_4M") == nullptr;
     auto corr_fn = corr_ts == 2 ? (corr_3m ? wpe_corr_kernel<2, true> : wpe_corr_kernel<2, false>)
                                 : (corr_3m ? wpe_corr_kernel<3, true> : wpe_corr_kernel<3, false>);
     const size_t corr_lds = sizeof(cplx) * (size_t)(CORR_KT + c + padf) * D + sizeof(double) * CORR_KT;
