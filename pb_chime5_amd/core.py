@@ -206,6 +206,7 @@ class Enhancer:
 
     device_id: int = None
     iterator_factory: object = field(default=None, repr=False)
+    inflight: int = 2        # utterances kept in flight per GPU by enhance_session
 
     # ------------------------------------------------------------------ STFT
     def stft(self, x):
@@ -259,20 +260,67 @@ class Enhancer:
             else:
                 raise ValueError(dataset_slice)
 
-        for ex in parallel.split_managed(it):
-            x_hat = self.enhance_example(ex)
-            example_id = ex['example_id']
-            session_id = ex['session_id']
-            dataset = mapping.session_to_dataset[session_id]
-            if x_hat.ndim == 1:
-                dump_audio(x_hat, audio_dir / f'{dataset}' / f'{example_id}.wav')
-            else:
-                raise NotImplementedError(x_hat.shape)
+        self._enhance_and_write(parallel.split_managed(it), audio_dir)
+
+    def _write(self, ex, x_hat, audio_dir):
+        dataset = mapping.session_to_dataset[ex['session_id']]
+        if x_hat.ndim == 1:
+            dump_audio(x_hat, Path(audio_dir) / f'{dataset}' / f'{ex["example_id"]}.wav')
+        else:
+            raise NotImplementedError(x_hat.shape)
+
+    def _enhance_and_write(self, examples, audio_dir):
+        """Enhance the examples and write ``audio_dir/<dataset>/<example_id>.wav``.
+        With the fused device pipeline ``self.inflight`` (default 2) utterances are kept
+        in flight on separate HIP streams: the host loads the next example's audio
+        while the GPU works, and one utterance's latency-bound kernels overlap the
+        other's compute-bound ones.  Results are identical to the one-at-a-time loop."""
+        if self.inflight <= 1 or not self._fusable():
+            for ex in examples:
+                try:
+                    self._write(ex, self.enhance_example(ex), audio_dir)
+                except Exception:
+                    print('ERROR: Failed example:', ex.get('example_id'))
+                    raise
+            return
+        pipe = ops.UtterancePipeline(self._params(), depth=self.inflight, first_ctx=self._ctx())
+        try:
+            for ex in examples:
+                try:
+                    obs, ex_array_activity, speaker_id = self._prepare_example(ex)
+                    target = tuple(ex_array_activity.keys()).index(speaker_id)
+                    activity = np.array(list(ex_array_activity.values()))
+                    start_ctx = end_ctx = 0
+                    if self.bf_drop_context:
+                        start_ctx, end_ctx = start_end_context_samples(ex)
+                    if pipe.full():
+                        done, x_hat = pipe.pop()
+                        self._write(done, self._trim_context(x_hat, done), audio_dir)
+                    pipe.enqueue(ex, obs, activity, target, start_ctx, end_ctx)
+                except Exception:
+                    print('ERROR: Failed example:', ex.get('example_id'))
+                    raise
+            while len(pipe):
+                done, x_hat = pipe.pop()
+                self._write(done, self._trim_context(x_hat, done), audio_dir)
+        finally:
+            pipe.close()
 
     # ------------------------------------------------------------------ examples
     def enhance_example(self, ex, debug=False):
         """core.py:396-512."""
-        session_id = ex['session_id']
+        obs, ex_array_activity, speaker_id = self._prepare_example(ex)
+        x_hat = self.enhance_observation(
+            obs, ex_array_activity=ex_array_activity, speaker_id=speaker_id, ex=ex,
+            debug=debug)
+        x_hat = self._trim_context(x_hat, ex)
+        if debug:
+            self.enhance_example_locals = dict(
+                ex=ex, obs=obs, ex_array_activity=ex_array_activity, speaker_id=speaker_id,
+                x_hat=x_hat)
+        return x_hat
+
+    def _reference_array(self, ex):
         reference_array = self.reference_array
         if reference_array is None:
             try:
@@ -286,6 +334,13 @@ class Enhancer:
                     'reference_array="U06").\n'
                     'In case of multiarray, the reference array is used for the '
                     'projection of the human annotations.') from None
+        return reference_array
+
+    def _prepare_example(self, ex):
+        """Host side of enhance_example (core.py:396-490): activity slices of the
+        reference array, channel selection, arrays cut to the shortest."""
+        session_id = ex['session_id']
+        reference_array = self._reference_array(ex)
         speaker_id = ex['speaker_id']
 
         array_start = ex['start']['observation'][reference_array]
@@ -321,20 +376,17 @@ class Enhancer:
                              stop=ex['end']['observation'][reference_array])
         else:
             raise ValueError(self.multiarray)
+        return obs, ex_array_activity, speaker_id
 
-        x_hat = self.enhance_observation(
-            obs, ex_array_activity=ex_array_activity, speaker_id=speaker_id, ex=ex,
-            debug=debug)
-
+    def _trim_context(self, x_hat, ex):
+        """core.py:500-505: cut the enhanced signal back to the original utterance."""
         if self.context_samples > 0:
+            reference_array = self._reference_array(ex)
             start_orig = ex['start_orig']['observation'][reference_array]
             start = ex['start']['observation'][reference_array]
             start_context = start_orig - start
             num_samples_orig = ex['num_samples_orig']['observation'][reference_array]
             x_hat = x_hat[..., start_context:start_context + num_samples_orig]
-
-        if debug:
-            self.enhance_example_locals = locals()
         return x_hat
 
     # ------------------------------------------------------------------ the hot path

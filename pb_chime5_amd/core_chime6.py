@@ -60,8 +60,8 @@ class Enhancer(core.Enhancer):
             drop_unknown_target_speaker=True, context_samples=self.context_samples,
             equal_start_context=False)
 
-    def enhance_example(self, ex, debug=False):
-        """core_chime6.py:396-510."""
+    def _prepare_example(self, ex):
+        """Host side of core_chime6.py:396-487: one clock for activity and all arrays."""
         session_id = ex['session_id']
         speaker_id = ex['speaker_id']
         array_start, array_end = ex['start'], ex['end']
@@ -86,31 +86,16 @@ class Enhancer(core.Enhancer):
         elif self.multiarray == 'first_array_mics':
             obs = load_arrays(lambda v: v[(0,), :])
         elif self.multiarray is False:
-            reference_array = self.reference_array
-            if reference_array is None:
-                try:
-                    reference_array = ex['reference_array']
-                except KeyError:
-                    raise RuntimeError(
-                        'Failed to get the "reference_array" from the example.\n'
-                        'Probably you tried to enhance the "train" dataset.\n'
-                        'Train has no "reference_array".\n'
-                        'You can set a "reference_array" with get_enhancer('
-                        'reference_array="U06").') from None
-            obs = load_audio(ex['audio_path']['observation'][reference_array],
+            obs = load_audio(ex['audio_path']['observation'][self._reference_array(ex)],
                              start=array_start, stop=array_end)
         else:
             raise ValueError(self.multiarray)
+        return obs, ex_array_activity, speaker_id
 
-        x_hat = self.enhance_observation(
-            obs, ex_array_activity=ex_array_activity, speaker_id=speaker_id, ex=ex,
-            debug=debug)
-
+    def _trim_context(self, x_hat, ex):
         if self.context_samples > 0:
             start_context = ex['start_orig'] - ex['start']
             x_hat = x_hat[..., start_context:start_context + ex['num_samples_orig']]
-        if debug:
-            self.enhance_example_locals = locals()
         return x_hat
 
 

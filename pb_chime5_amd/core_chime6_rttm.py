@@ -73,34 +73,21 @@ class Enhancer(core.Enhancer):
                 raise ValueError(dataset_slice)
         # hand out indices, not loaded examples: audio is read by the rank that works
         costs = [ex['num_samples'] for ex in it.examples]
-        for index in parallel.split_managed(range(len(it)), costs=costs):
-            ex = it[index]
-            try:
-                x_hat = self.enhance_example(ex)
-                dataset = mapping.session_to_dataset[ex['session_id']]
-                if x_hat.ndim == 1:
-                    dump_audio(x_hat, audio_dir / f'{dataset}' / f'{ex["example_id"]}.wav')
-                else:
-                    raise NotImplementedError(x_hat.shape)
-            except Exception:
-                print('ERROR: Failed example:', ex['example_id'])
-                raise
+        indices = parallel.split_managed(range(len(it)), costs=costs)
+        self._enhance_and_write((it[index] for index in indices), audio_dir)
 
-    def enhance_example(self, ex, debug=False):
-        session_id = ex['session_id']
-        speaker_id = ex['speaker_id']
+    def _prepare_example(self, ex):
+        """core_chime6_rttm.py:228-258: the audio came with the example."""
         array_start, array_end = ex['start'], ex['end']
         ex_array_activity = {
-            k: arr[array_start:array_end] for k, arr in self.activity[session_id].items()
+            k: arr[array_start:array_end] for k, arr in self.activity[ex['session_id']].items()
         }
-        obs = ex['audio_data']
-        x_hat = self.enhance_observation(obs, ex_array_activity=ex_array_activity,
-                                         speaker_id=speaker_id, ex=ex, debug=debug)
+        return ex['audio_data'], ex_array_activity, ex['speaker_id']
+
+    def _trim_context(self, x_hat, ex):
         if self.context_samples > 0:
             start_context = ex['start_orig'] - ex['start']
             x_hat = x_hat[..., start_context:start_context + ex['num_samples_orig']]
-        if debug:
-            self.enhance_example_locals = locals()
         return x_hat
 
 

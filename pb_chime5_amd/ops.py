@@ -20,7 +20,7 @@ import ctypes
 import numpy as np
 
 from . import _capi
-from ._capi import GssDebugTaps, GssParams, c_void_p, default_context
+from ._capi import Context, GssDebugTaps, GssParams, c_void_p, default_context
 
 _BF_CODES = {'mvdrSouden_ban': 0, 'ch2': 1, 'sum': 2, 'gev_ban': 3}
 _POSTFILTER_CODES = {None: 0, 'mask_mul': 1}
@@ -292,6 +292,83 @@ class ResidentUtterance:
 
     def result(self):
         return self.ctx.to_host(self.out_d, (self.n_out,), np.float64)
+
+
+class UtterancePipeline:
+    """Keeps up to ``depth`` utterances in flight on one GPU, each on its own context
+    (HIP stream + workspace), so that one utterance's latency-bound kernels overlap the
+    other's MFMA / VALU-bound ones and host work (audio I/O, H2D, D2H, writing) overlaps
+    device work -- SURVEY.md section 8e "keep >= 2 utterances in flight per GPU".
+
+        pipe = UtterancePipeline(params, depth=2)
+        for ex in examples:
+            prepared = load(ex)                       # host work first ...
+            if pipe.full():
+                tag, x_hat = pipe.pop()               # ... then wait for the oldest
+            pipe.enqueue(ex, *prepared)
+        while len(pipe): tag, x_hat = pipe.pop()
+
+    Device buffers are per slot and grow-only (no hipMalloc / hipFree between
+    utterances: hipFree synchronises the whole device)."""
+
+    def __init__(self, params, depth=2, device_id=None, window=None, first_ctx=None):
+        from collections import deque
+        assert depth >= 1
+        first = first_ctx or default_context(device_id)
+        self.params = params
+        self.slots = [first] + [Context(first.device_id) for _ in range(depth - 1)]
+        for c in self.slots:
+            _prepare_windows(c, params.stft_size, params.stft_shift, window)
+        self._bufs = [dict() for _ in self.slots]
+        self._pending = deque()
+        self._next = 0
+
+    def __len__(self):
+        return len(self._pending)
+
+    def full(self):
+        return len(self._pending) == len(self.slots)
+
+    def _buffer(self, slot, name, nbytes):
+        buf = self._bufs[slot].get(name)
+        if buf is None or buf.nbytes < nbytes:
+            buf = self._bufs[slot][name] = self.slots[slot].empty(max(int(nbytes * 1.25), 16))
+        return buf
+
+    def enqueue(self, tag, obs, activity, target_index, start_context, end_context):
+        assert not self.full(), 'pop() the oldest utterance first'
+        slot = self._next
+        self._next = (self._next + 1) % len(self.slots)
+        ctx, p = self.slots[slot], self.params
+        obs = np.ascontiguousarray(obs, dtype=np.float64)
+        act = np.ascontiguousarray((np.asarray(activity) != 0).astype(np.uint8))
+        D, N = obs.shape
+        K, N_act = act.shape
+        T = stft_frames(N, p.stft_size, p.stft_shift, p.stft_fading)
+        n_out = int(ctx.lib.gss_istft_num_samples(T, p.stft_size, p.stft_shift, p.stft_fading))
+        obs_d = self._buffer(slot, 'obs', obs.nbytes)
+        act_d = self._buffer(slot, 'act', act.nbytes)
+        out_d = self._buffer(slot, 'out', 8 * max(n_out, 1))
+        ctx.upload(obs_d, obs)
+        ctx.upload(act_d, act)
+        ctx._check(ctx.lib.gss_enhance_observation(
+            ctx.handle, ctypes.byref(p), c_void_p(obs_d.ptr), D, N, c_void_p(act_d.ptr), K,
+            N_act, int(target_index), int(start_context), int(end_context),
+            c_void_p(out_d.ptr), None), 'gss_enhance_observation')
+        self._pending.append((tag, slot, n_out))
+
+    def pop(self):
+        tag, slot, n_out = self._pending.popleft()
+        x_hat = self.slots[slot].to_host(self._bufs[slot]['out'], (n_out,), np.float64)
+        return tag, x_hat
+
+    def close(self):
+        while self._pending:
+            self.pop()
+        self._bufs = [dict() for _ in self.slots]
+        for c in self.slots[1:]:
+            c.close()
+        self.slots = self.slots[:1]
 
 
 def enhance_observation(obs, activity, target_index, start_context_samples,

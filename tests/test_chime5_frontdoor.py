@@ -249,6 +249,24 @@ def test_enhance_session_writes_reference_layout(corpus, fixture, tmp_path):
     assert len(list(audio_dir.rglob('*.wav'))) == 3       # examples 0, 5 and now 1
 
 
+@pytest.mark.gpu
+def test_pipelined_session_equals_sequential(corpus, fixture, tmp_path):
+    """enhance_session keeps two utterances in flight; the files must be byte-identical
+    to the one-at-a-time loop."""
+    a, b = tmp_path / 'seq', tmp_path / 'pipe'
+    seq = _enhancer(corpus, fixture)
+    seq.inflight = 1
+    seq.enhance_session('S02', a)
+    pipe = _enhancer(corpus, fixture)
+    assert pipe.inflight == 2
+    pipe.enhance_session('S02', b)
+    files = sorted(p.relative_to(a) for p in a.rglob('*.wav'))
+    assert len(files) == len(fixture['examples'])
+    assert files == sorted(p.relative_to(b) for p in b.rglob('*.wav'))
+    for rel in files:
+        assert (a / rel).read_bytes() == (b / rel).read_bytes(), rel
+
+
 # ---------------------------------------------------------------- command line
 def test_cli_config_parsing():
     from pb_chime5_amd.scripts import run, kaldi_run, kaldi_run_rttm

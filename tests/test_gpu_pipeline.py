@@ -365,3 +365,36 @@ def test_unsupported_sizes_fail_loudly(gpu_ctx):
         ops.stft(np.zeros(4000), size=1000, shift=250)
     with pytest.raises(ValueError):
         ops.enhance_observation(np.zeros((2, 4000)), np.ones((2, 100), bool), 0, 0, 0)
+
+
+def test_utterance_pipeline_is_bit_identical_to_one_at_a_time(gpu_ctx):
+    """ops.UtterancePipeline (several utterances in flight on separate HIP streams, slot
+    buffers reused across utterances of different sizes) returns exactly what the
+    one-at-a-time path returns, in submission order."""
+    from pb_chime5_amd import ops, synthetic
+    utts = [synthetic.tiny(seed=s, num_channels=c, num_samples=n, num_speakers=k)
+            for s, c, n, k in [(1, 4, 12000, 2), (2, 6, 20000, 3), (3, 4, 9000, 2),
+                               (4, 8, 16000, 2), (5, 6, 20000, 3)]]
+    kw = dict(wpe=True, wpe_taps=3, wpe_iterations=2, bss_iterations=4)
+    params = ops.make_params(**kw)
+    want = []
+    for u in utts:
+        cs = u.ex['start_orig']['original']
+        want.append(ops.enhance_observation(u.obs, u.activity_array, u.target_index, cs, cs,
+                                            params=params, ctx=gpu_ctx))
+    for depth in (1, 2, 3):
+        pipe = ops.UtterancePipeline(params, depth=depth, first_ctx=gpu_ctx)
+        got = {}
+        for i, u in enumerate(utts):
+            cs = u.ex['start_orig']['original']
+            if pipe.full():
+                tag, x = pipe.pop()
+                got[tag] = x
+            pipe.enqueue(i, u.obs, u.activity_array, u.target_index, cs, cs)
+        while len(pipe):
+            tag, x = pipe.pop()
+            got[tag] = x
+        pipe.close()
+        assert sorted(got) == list(range(len(utts)))
+        for i, w in enumerate(want):
+            assert np.array_equal(got[i], w), (depth, i)
