@@ -52,6 +52,7 @@ SIGNATURES = {
     'gss_memcpy_d2h': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     'gss_memset': (c_int, [c_void_p, c_void_p, c_int, c_size_t]),
     'gss_profile_enable': (c_int, [c_void_p, c_int]),
+    'gss_profile_filter': (c_int, [c_void_p, ctypes.c_char_p]),
     'gss_profile_reset': (c_int, [c_void_p]),
     'gss_profile_report': (c_int, [c_void_p, ctypes.c_char_p, c_size_t]),
     'gss_stft_num_frames': (c_int64, [c_int64, c_int, c_int, c_int]),
@@ -226,6 +227,10 @@ class Context:
     # -- profiling ---------------------------------------------------------
     def profile_enable(self, on=True):
         self._check(self.lib.gss_profile_enable(self.handle, int(on)), 'profile_enable')
+
+    def profile_filter(self, kernel=None):
+        self._check(self.lib.gss_profile_filter(
+            self.handle, kernel.encode() if kernel else None), 'profile_filter')
 
     def profile_reset(self):
         self._check(self.lib.gss_profile_reset(self.handle), 'profile_reset')

@@ -178,6 +178,7 @@ extern "C" size_t gss_workspace_bytes(gss_ctx *ctx) { return ctx ? ctx->arena_pe
 
 // ------------------------------------------------------------------ profiling
 ProfScope::ProfScope(gss_ctx *c, const char *name) : ctx(c), active(c->profiling) {
+    if (active && !c->prof_filter.empty() && c->prof_filter != name) active = false;
     if (!active) return;
     e.name = name;
     auto get = [&]() {
@@ -219,6 +220,12 @@ static void prof_drain(gss_ctx *ctx) {
 extern "C" int gss_profile_enable(gss_ctx *ctx, int on) {
     if (!ctx) return GSS_ERR_INVALID;
     ctx->profiling = on != 0;
+    return GSS_OK;
+}
+
+extern "C" int gss_profile_filter(gss_ctx *ctx, const char *kernel) {
+    if (!ctx) return GSS_ERR_INVALID;
+    ctx->prof_filter = kernel ? kernel : "";
     return GSS_OK;
 }
 

@@ -119,6 +119,7 @@ struct gss_ctx {
     std::vector<ProfEntry> prof_pending;
     std::vector<hipEvent_t> event_pool;
     std::map<std::string, std::pair<long, double>> prof_acc;
+    std::string prof_filter;   // time only this kernel (empty: all)
 };
 
 int gss_fail(gss_ctx *ctx, int code, const char *fmt, ...);
