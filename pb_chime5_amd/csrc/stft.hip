@@ -53,12 +53,16 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx *s = reinterpret_cast<cplx *>(smem);            // PAIRS * size
     cplx *tw = s + PAIRS * size;                          // size / 2
+    unsigned *nz = reinterpret_cast<unsigned *>(tw + size / 2);   // bit c: channel c non-zero
     const int64_t t = blockIdx.x;
     const int d0 = blockIdx.y * 2 * PAIRS;
     const int F = size / 2 + 1;
 
+    if (threadIdx.x == 0) *nz = 0u;
     for (int i = threadIdx.x; i < size / 2; i += blockDim.x) tw[i] = twiddle[i];
+    __syncthreads();
     const int64_t n0 = t * shift - pad;
+    unsigned mine = 0u;
     for (int idx = threadIdx.x; idx < PAIRS * size; idx += blockDim.x) {
         const int pr = idx / size;
         const int i = idx - pr * size;
@@ -71,11 +75,20 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_kernel(
             if (db < D) vb = x[(int64_t)db * N + n] * w;
         }
         s[pr * size + bitrev(i, log2n)] = c_make(va, vb);
+        if (va != 0.0) mine |= 1u << (2 * pr);
+        if (vb != 0.0) mine |= 1u << (2 * pr + 1);
     }
+    if (mine) atomicOr(nz, mine);
     __syncthreads();
     fft_lds(s, size, log2n, PAIRS, tw, false);
 
     // Z = FFT(a + i b):  A[f] = (Z[f] + conj(Z[n-f])) / 2,  B[f] = (Z[f] - conj(Z[n-f])) / (2i)
+    // The separation leaks ~1e-16 of the partner channel.  An all-zero frame (a dead
+    // microphone, digital silence) must come out as exact zeros, as rfft gives in the
+    // reference: an exactly singular WPE correlation matrix takes the reference's lstsq
+    // branch (math/solve.py:95-114, minimum norm = zero taps on the dead channel), an almost
+    // singular one would be solved with taps of size 1e16 on the leaked noise.
+    const unsigned nonzero = *nz;
     const int nch = min(2 * PAIRS, D - d0);
     for (int idx = threadIdx.x; idx < F * nch; idx += blockDim.x) {
         const int f = idx / nch;
@@ -89,6 +102,7 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_kernel(
         } else {
             v = c_make(0.5 * (z.y + zc.y), 0.5 * (zc.x - z.x));
         }
+        if (!((nonzero >> c) & 1u)) v = c_make(0.0, 0.0);
         Y[((int64_t)f * T + t) * D + d0 + c] = v;
     }
 }
@@ -269,13 +283,13 @@ int stft_run(gss_ctx *ctx, const double *x, int D, int64_t N, int fading, cplx *
     if (size <= 1024) {
         constexpr int PAIRS = 4;
         dim3 grid((unsigned)T, (D + 2 * PAIRS - 1) / (2 * PAIRS));
-        size_t lds = sizeof(cplx) * (PAIRS * size + size / 2);
+        size_t lds = sizeof(cplx) * (PAIRS * size + size / 2) + 16;
         hipLaunchKernelGGL(stft_kernel<PAIRS>, grid, dim3(FFT_THREADS), lds, ctx->stream, x, D, N,
                            T, size, ilog2(size), shift, pad, ctx->win_analysis, ctx->twiddle, Y);
     } else {
         constexpr int PAIRS = 1;
         dim3 grid((unsigned)T, (D + 1) / 2);
-        size_t lds = sizeof(cplx) * (PAIRS * size + size / 2);
+        size_t lds = sizeof(cplx) * (PAIRS * size + size / 2) + 16;
         hipLaunchKernelGGL(stft_kernel<PAIRS>, grid, dim3(FFT_THREADS), lds, ctx->stream, x, D, N,
                            T, size, ilog2(size), shift, pad, ctx->win_analysis, ctx->twiddle, Y);
     }

@@ -325,6 +325,23 @@ def test_edge_target_never_active_and_silent_speaker(gpu_ctx):
     assert rel_err(got, want) < 1e-4
 
 
+def test_edge_dead_microphone_takes_the_lstsq_branch(gpu_ctx):
+    """One microphone delivers digital zeros: its STFT must be EXACT zeros so that the WPE
+    correlation matrix is exactly singular, np.linalg.solve raises in the reference and
+    stable_solve falls back to the minimum-norm lstsq solution (math/solve.py:95-114) --
+    zero taps on the dead channel.  (A two-for-one real FFT leaks 1e-16 of the partner
+    channel; the STFT kernel zeroes all-zero frames explicitly.)"""
+    from pb_chime5_amd import synthetic
+    u = synthetic.tiny(seed=3, num_channels=6, num_samples=24000, num_speakers=2)
+    u.obs[2] = 0.0
+    got, det, want, wdet = _run_both(u, wpe=True, wpe_taps=4, wpe_delay=2, wpe_iterations=2,
+                                     bss_iterations=5)
+    assert np.all(det['Obs'][2] == 0) and np.all(wdet['Obs'][2] == 0)
+    assert rel_err(det['Obs'], wdet['Obs']) < 1e-5
+    assert rel_err(np.abs(det['X_hat']), np.abs(wdet['X_hat'])) < TOL_STFT_MAG
+    assert rel_err(got, want) < TOL_STFT_MAG
+
+
 def test_edge_all_zero_observation_gives_nan_like_reference(gpu_ctx):
     """Digital silence: PSD matrices are zero, solve falls back to lstsq -> w = 0, and
     BAN divides 0 / 0 (eps = 0 upstream), so the reference returns NaN everywhere.
