@@ -116,16 +116,21 @@ def main():
             raise SystemExit('launch with torch.distributed.run for --gpus > 1')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an AMD GPU (there is no CPU fallback for the hot path)')
-    torch.cuda.set_device(local_rank)
+    # GSS_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised on a box with
+    # fewer GPUs than ranks (ranks then share devices); the driver's runs use RCCL.
+    backend = os.environ.get('GSS_BENCH_BACKEND', 'nccl')
+    device_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    coll_device = 'cuda' if backend == 'nccl' else 'cpu'
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend='nccl')
+        dist.init_process_group(backend=backend)
 
     from pb_chime5_amd import ops, roofline, synthetic
     from pb_chime5_amd._capi import Context
 
-    ctx = Context(local_rank)
+    ctx = Context(device_index)
     params = ops.make_params(wpe=True, wpe_taps=WORKLOAD['wpe_taps'],
                              wpe_delay=WORKLOAD['wpe_delay'],
                              wpe_iterations=WORKLOAD['wpe_iterations'],
@@ -165,7 +170,7 @@ def main():
     dominant = max(prof_all, key=lambda k: prof_all[k]['ms'])
     if dist is not None:       # every rank times the same kernel
         names = sorted(prof_all)
-        idx = torch.tensor([names.index(dominant)], device='cuda')
+        idx = torch.tensor([names.index(dominant)], device=coll_device)
         dist.broadcast(idx, src=0)
         dominant = names[int(idx.item())]
     ctx.profile_filter(dominant)
@@ -211,7 +216,7 @@ def main():
         pipe.close()
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
