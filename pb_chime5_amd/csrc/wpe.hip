@@ -51,31 +51,33 @@ __global__ __launch_bounds__(256) void wpe_power_kernel(const cplx *__restrict__
 constexpr int CORR_KT = 64;   // frames staged per chunk
 
 struct CorrTile {
-    int row_off, col_off, is_p, pad;
+    int row_off, col_off, is_p, mask;   // mask: needed 16 x 16 sub-tiles, bit a * TS + b
 };
 
 // 1-D XCD-mapped grid over (tile groups, F); block: 256 = 4 waves, one
-// (16 TS) x (16 TS) tile each.
-template <int TS, bool M3>
-__global__ __launch_bounds__(256) void wpe_corr_kernel(
-    const cplx *__restrict__ Y, const double *__restrict__ w, int F, int64_t T, int D, int n,
-    int c, int padf, const CorrTile *__restrict__ tiles, int ntiles, cplx *__restrict__ R,
-    cplx *__restrict__ P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int frames_lds = CORR_KT + c + padf;
-    cplx *S = reinterpret_cast<cplx *>(smem);                      // frames_lds * D
-    double *wS = reinterpret_cast<double *>(S + frames_lds * D);   // CORR_KT
-
-    int f, grp;
-    if (!xcd_group_map((ntiles + 3) / 4, F, f, grp)) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile_id = grp * 4 + wave;
-    const bool active = tile_id < ntiles;
-    CorrTile tl = tiles[active ? tile_id : 0];
+// (16 TS) x (16 TS) tile each.  MASK (bit a * TS + b) says which 16 x 16 sub-tiles of
+// the wave's tile are needed: diagonal tiles skip the sub-tile below the diagonal and
+// tiles on the edge of n (240 = 7.5 x 32) the half that lies outside, which removes
+// 15 % of the MFMAs at taps * D = 240.  The host sorts the tile list by mask so that the
+// four waves of a workgroup carry similar loads.
+template <int TS, bool M3, int MASK>
+__device__ __forceinline__ void corr_tile_body(
+    const cplx *__restrict__ Yf, const double *__restrict__ wf, int64_t T, int D, int n, int c,
+    int frames_lds, cplx *S, double *wS, const CorrTile tl, bool active, int f,
+    cplx *__restrict__ R, cplx *__restrict__ P) {
+    const int lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
-    const cplx *Yf = Y + (int64_t)f * T * D;
-    const double *wf = w + (int64_t)f * T;
-
+    auto need = [](int a, int b) { return ((MASK >> (a * TS + b)) & 1) != 0; };
+    auto need_row = [&](int a) {
+        bool r = false;
+        for (int b = 0; b < TS; ++b) r = r || need(a, b);
+        return r;
+    };
+    auto need_col = [&](int b) {
+        bool r = false;
+        for (int a = 0; a < TS; ++a) r = r || need(a, b);
+        return r;
+    };
     // 3M complex product: with t1 = sum ar br, t2 = sum ai bi, t3 = sum (ar+ai)(br-bi)
     //   re(a conj b) = t1 + t2,   im(a conj b) = t3 - t1 + t2
     // -- three real MFMAs per tile and k-step instead of four.
@@ -148,8 +150,8 @@ __global__ __launch_bounds__(256) void wpe_corr_kernel(
                 w_nxt = wS[kf];
 #pragma unroll
                 for (int m = 0; m < TS; ++m) {
-                    a_nxt[m] = base[tl.row_off + 16 * m];
-                    b_nxt[m] = base[tl.col_off + 16 * m];
+                    a_nxt[m] = need_row(m) ? base[tl.row_off + 16 * m] : c_make(0.0, 0.0);
+                    b_nxt[m] = need_col(m) ? base[tl.col_off + 16 * m] : c_make(0.0, 0.0);
                 }
             }
             double ar[TS], ai[TS], as[TS], br[TS], bi[TS], bd[TS];
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(256) void wpe_corr_kernel(
                 for (int a = 0; a < TS; ++a)
 #pragma unroll
                     for (int b = 0; b < TS; ++b) {
+                        if (!need(a, b)) continue;
                         t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], br[b], t1[a][b], 0, 0, 0);
                         t2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], bi[b], t2[a][b], 0, 0, 0);
                         t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[a], bd[b], t3[a][b], 0, 0, 0);
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(256) void wpe_corr_kernel(
                 for (int a = 0; a < TS; ++a)
 #pragma unroll
                     for (int b = 0; b < TS; ++b) {
+                        if (!need(a, b)) continue;
                         t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], br[b], t1[a][b], 0, 0, 0);
                         t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], br[b], t3[a][b], 0, 0, 0);
                     }
@@ -184,6 +188,7 @@ __global__ __launch_bounds__(256) void wpe_corr_kernel(
                 for (int a = 0; a < TS; ++a)
 #pragma unroll
                     for (int b = 0; b < TS; ++b) {
+                        if (!need(a, b)) continue;
                         t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], bi[b], t1[a][b], 0, 0, 0);
                         t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], -bi[b], t3[a][b], 0, 0, 0);
                     }
@@ -206,6 +211,7 @@ __global__ __launch_bounds__(256) void wpe_corr_kernel(
         for (int b = 0; b < TS; ++b)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
+                if (!need(a, b)) continue;
                 const int r = tl.row_off + 16 * a + lk + 4 * reg;
                 const int cc = tl.col_off + 16 * b + li;
                 const cplx v = M3 ? c_make(t1[a][b][reg] + t2[a][b][reg],
@@ -219,6 +225,43 @@ __global__ __launch_bounds__(256) void wpe_corr_kernel(
                     Rf[r * n + cc] = v;
                 }
             }
+}
+
+template <int TS, bool M3>
+__global__ __launch_bounds__(256) void wpe_corr_kernel(
+    const cplx *__restrict__ Y, const double *__restrict__ w, int F, int64_t T, int D, int n,
+    int c, int padf, const CorrTile *__restrict__ tiles, int ntiles, cplx *__restrict__ R,
+    cplx *__restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int frames_lds = CORR_KT + c + padf;
+    cplx *S = reinterpret_cast<cplx *>(smem);                      // frames_lds * D
+    double *wS = reinterpret_cast<double *>(S + frames_lds * D);   // CORR_KT
+
+    int f, grp;
+    if (!xcd_group_map((ntiles + 3) / 4, F, f, grp)) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile_id = grp * 4 + wave;
+    const bool active = tile_id < ntiles;
+    const CorrTile tl = tiles[active ? tile_id : 0];
+    const cplx *Yf = Y + (int64_t)f * T * D;
+    const double *wf = w + (int64_t)f * T;
+    constexpr int FULL = (1 << (TS * TS)) - 1;
+    const int mask = __builtin_amdgcn_readfirstlane(active ? tl.mask : 1);
+#define CORR_CASE(M) \
+    case M: corr_tile_body<TS, M3, M>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P); break
+    if (TS == 2) {
+        switch (mask) {
+            CORR_CASE(1);
+            CORR_CASE(3);
+            CORR_CASE(5);
+            CORR_CASE(11);
+            default:
+                corr_tile_body<TS, M3, FULL>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P);
+        }
+    } else {
+        corr_tile_body<TS, M3, FULL>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P);
+    }
+#undef CORR_CASE
 }
 
 // ------------------------------------------------------------------ solve
@@ -797,12 +840,30 @@ __global__ void mfma_selftest_kernel(double *out) {
 }  // namespace
 
 static int corr_tiles(int n, int D, int c, int ct, std::vector<CorrTile> &tiles) {
-    // R: every ct x ct tile that reaches the upper triangle; P: all rows x D columns
+    // R: every ct x ct tile that reaches the upper triangle; P: all rows x D columns.
+    // mask = the 16 x 16 sub-tiles that hold at least one needed entry.
+    const int ts = ct / 16;
+    auto mask_of = [&](int r0, int c0, int ncols_limit, bool upper_only) {
+        int m = 0;
+        for (int a = 0; a < ts; ++a)
+            for (int b = 0; b < ts; ++b) {
+                const int rr = r0 + 16 * a, cc = c0 + 16 * b;
+                bool needed = rr < n && cc < ncols_limit;
+                if (upper_only && cc + 15 < rr) needed = false;     // entirely below the diagonal
+                if (needed) m |= 1 << (a * ts + b);
+            }
+        return m;
+    };
     for (int r0 = 0; r0 < n; r0 += ct)
         for (int c0 = 0; c0 < n; c0 += ct)
-            if (c0 + ct > r0) tiles.push_back({r0, c0, 0, 0});
+            if (c0 + ct > r0) tiles.push_back({r0, c0, 0, mask_of(r0, c0, n, true)});
     for (int r0 = 0; r0 < n; r0 += ct)
-        for (int c0 = 0; c0 < D; c0 += ct) tiles.push_back({r0, c * D + c0, 1, 0});
+        for (int c0 = 0; c0 < D; c0 += ct)
+            tiles.push_back({r0, c * D + c0, 1, mask_of(r0, c0, D, false)});
+    // heaviest first, so that the four waves of a workgroup carry similar loads
+    std::stable_sort(tiles.begin(), tiles.end(), [](const CorrTile &x, const CorrTile &y) {
+        return __builtin_popcount(x.mask) > __builtin_popcount(y.mask);
+    });
     return (int)tiles.size();
 }
 

@@ -26,14 +26,13 @@ def kernel_work(name, *, F, T, D, K, taps, N):
     n = taps * D
     if name == 'wpe_corr':
         # R = (Yt w) Yt^H : 8 n^2 T ;  P = (Yt w) Y^H : 8 n D T   per frequency (the
-        # dense count of SURVEY 8d).  The kernel exploits R = R^H: it computes the 32 x 32
-        # tiles that reach the upper triangle plus the P tiles, `executed` of the dense.
-        ct = 32
-        nt = -(-n // ct)
-        tiles = sum(1 for r in range(nt) for c in range(nt) if (c + 1) * ct > r * ct)
-        tiles_p = nt * -(-D // ct)
+        # dense count of SURVEY 8d).  The kernel exploits R = R^H: of its 32 x 32 wave tiles
+        # it computes the 16 x 16 sub-tiles that hold an entry of the upper triangle (or of
+        # P), `executed` of the dense count ...
+        sub = -(-n // 16)
+        subtiles = sub * (sub + 1) // 2 + sub * -(-D // 16)
         # ... and forms each complex product with 3 real MFMAs instead of 4 (x 0.75).
-        executed = 0.75 * (tiles + tiles_p) * ct * ct / float(n * n + n * D)
+        executed = 0.75 * subtiles * 256 / float(n * n + n * D)
         return dict(flops=F * (8.0 * n * n * T + 8.0 * n * D * T), bytes=BY + 8.0 * F * T,
                     bound='mfma', executed=executed)
     if name == 'wpe_solve':
