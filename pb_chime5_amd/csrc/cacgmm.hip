@@ -578,34 +578,19 @@ __device__ inline void store_covariance(const cplx (&vals)[COV_SLOTS], int D, do
 //
 // Factor and inverse come from ONE register-resident sweep (chol_inverse_sweep,
 // 8 x 8 lane grid, NR x NR entries per lane, D <= 8 NR).
+//
+// One class matrix by one wave (the wave may be part of a larger workgroup): `vals` holds
+// the packed upper triangle of B (entry e = lane + 64 s).  Writes Mq(:, k) and ln det and
+// returns whether the no-floor certificate holds; A = D * (8 NR + 1) complex + D doubles
+// of LDS owned by this wave.
 template <int NR>
-__global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp,
-                                                     const double *__restrict__ Sg, int nch,
-                                                     int sg_nch, int D,
-                                                     int K, int64_t T, double eig_floor,
-                                                     int force_eigh, cplx *__restrict__ Mq,
-                                                     double *__restrict__ logdet,
-                                                     double *__restrict__ pi,
-                                                     int *__restrict__ need_eigh) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ bool class_update_chol(const cplx (&vals)[COV_SLOTS], int D, int K,
+                                                  double eig_floor, cplx *A, int lane,
+                                                  cplx *__restrict__ Mq_fk,
+                                                  double *__restrict__ logdet_fk) {
     constexpr int ld = 8 * NR + 1;
     const int NE = tri_count(D);
-    cplx *A = reinterpret_cast<cplx *>(smem);                  // D * ld
-    double *dinv = reinterpret_cast<double *>(A + D * ld);     // D
-    const int k = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
-
-    double sg = 0.0;
-    for (int c = 0; c < sg_nch; ++c) sg += Sg[((int64_t)f * sg_nch + c) * K + k];
-    const double den = fmax(sg, GSS_TINY);
-    if (lane == 0) pi[f * K + k] = sg / (double)T;
-
-    cplx vals[COV_SLOTS];
-    const double tr = reduce_covariance(Bp, nch, D, K, k, f, den, vals, lane);
-    bool fast = !force_eigh && tr > 0.0 && isfinite(tr);
-    if (!fast) {
-        if (lane == 0) need_eigh[f * K + k] = 1;
-        return;
-    }
+    double *dinv = reinterpret_cast<double *>(A + D * ld);
     double nb2 = 0.0;   // ||B||_F^2 from the packed upper triangle
 #pragma unroll
     for (int s = 0; s < COV_SLOTS; ++s) {
@@ -618,7 +603,7 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
     }
     nb2 = wave_sum(nb2);
     store_covariance(vals, D, 0.0, true, A, ld, lane);
-    __syncthreads();
+    wave_sync();
     const int tx = lane & 7, ty = lane >> 3;
     cplx reg[NR][NR];
 #pragma unroll
@@ -628,12 +613,8 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
             const int i = ty + 8 * a, kk = tx + 8 * b;
             reg[a][b] = (kk >= i && kk < D) ? A[i * ld + kk] : c_make(0.0, 0.0);
         }
-    __syncthreads();
-    fast = chol_inverse_sweep<8, NR>(reg, D, A, ld, dinv, tx, ty);
-    if (!fast) {
-        if (lane == 0) need_eigh[f * K + k] = 1;
-        return;
-    }
+    wave_sync();
+    if (!chol_inverse_sweep<8, NR, true>(reg, D, A, ld, dinv, tx, ty)) return false;
     double ldv = 0.0;   // ln det B = 2 sum ln U_ii
     for (int i = lane; i < D; i += 64) ldv -= 2.0 * log(dinv[i]);
     ldv = wave_sum(ldv);
@@ -643,7 +624,7 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
         if (kk < i) A[i * ld + kk] = c_scale(A[i * ld + kk], dinv[i]);
         else if (kk == i) A[i * ld + i] = c_make(dinv[i], 0.0);
     }
-    __syncthreads();
+    wave_sync();
     // B^-1 = W^H W :  (d1,d2) = sum_{j >= d2} conj(W[j][d1]) W[j][d2]
     double ni2 = 0.0;
     for (int e = lane; e < NE; e += 64) {
@@ -659,44 +640,29 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
             v.x *= 2.0;
             v.y *= 2.0;
         }
-        Mq[((int64_t)f * NE + e) * K + k] = v;
+        Mq_fk[(int64_t)e * K] = v;
     }
     ni2 = wave_sum(ni2);
+    if (lane == 0) *logdet_fk = ldv;
     const double bound = 0.5 / eig_floor;
-    fast = isfinite(ni2) && nb2 * ni2 < bound * bound;
-    if (lane == 0) {
-        need_eigh[f * K + k] = fast ? 0 : 1;
-        logdet[f * K + k] = ldv;
-    }
+    return isfinite(ni2) && nb2 * ni2 < bound * bound;
 }
 
-// Eigendecomposition path for the flagged matrices: eigenvalues / max, floor, then
-// B^-1 = V diag(1/lambda) V^H and ln det = sum ln lambda, exactly as the reference.
-__global__ __launch_bounds__(64) void em_eigh_kernel(const cplx *__restrict__ Bp,
-                                                     const double *__restrict__ Sg, int nch,
-                                                     int sg_nch, int D,
-                                                     int K, double eig_floor,
-                                                     const int *__restrict__ need_eigh,
-                                                     cplx *__restrict__ Mq,
-                                                     double *__restrict__ logdet) {
-    const int k = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
-    if (!need_eigh[f * K + k]) return;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// Eigendecomposition path (exactly the reference): eigenvalues / max, floor, then
+// B^-1 = V diag(1/lambda) V^H and ln det = sum ln lambda.  A, V = m x m complex each and
+// lam = m doubles of LDS owned by this wave, m = D rounded up to even.
+__device__ inline void class_update_eigh(const cplx (&vals)[COV_SLOTS], int D, int K,
+                                         double eig_floor, cplx *A, int lane,
+                                         cplx *__restrict__ Mq_fk,
+                                         double *__restrict__ logdet_fk) {
     const int m = D + (D & 1);
     const int NE = tri_count(D);
-    cplx *A = reinterpret_cast<cplx *>(smem);   // m * m
-    cplx *V = A + m * m;                         // m * m
-    double *lam = reinterpret_cast<double *>(V + m * m);   // m
-
-    double sg = 0.0;
-    for (int c = 0; c < sg_nch; ++c) sg += Sg[((int64_t)f * sg_nch + c) * K + k];
-    const double den = fmax(sg, GSS_TINY);
+    cplx *V = A + m * m;
+    double *lam = reinterpret_cast<double *>(V + m * m);
     for (int idx = lane; idx < m * m; idx += 64) A[idx] = c_make(0.0, 0.0);
-    __syncthreads();
-    cplx vals[COV_SLOTS];
-    reduce_covariance(Bp, nch, D, K, k, f, den, vals, lane);
+    wave_sync();
     store_covariance(vals, D, 0.0, true, A, m, lane);
-    __syncthreads();
+    wave_sync();
     jacobi_eigh_wave(A, V, m, lane, 20);
     double lmax = -INFINITY;
     for (int i = lane; i < D; i += 64) lmax = fmax(lmax, A[i * m + i].x);
@@ -709,7 +675,7 @@ __global__ __launch_bounds__(64) void em_eigh_kernel(const cplx *__restrict__ Bp
         ldv += log(l);
     }
     ldv = wave_sum(ldv);
-    __syncthreads();
+    wave_sync();
     for (int e = lane; e < NE; e += 64) {
         int d1, d2;
         tri_unpack(e, D, d1, d2);
@@ -726,9 +692,58 @@ __global__ __launch_bounds__(64) void em_eigh_kernel(const cplx *__restrict__ Bp
             v.x *= 2.0;
             v.y *= 2.0;
         }
-        Mq[((int64_t)f * NE + e) * K + k] = v;
+        Mq_fk[(int64_t)e * K] = v;
     }
-    if (lane == 0) logdet[f * K + k] = ldv;
+    if (lane == 0) *logdet_fk = ldv;
+}
+
+template <int NR>
+__global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp,
+                                                     const double *__restrict__ Sg, int nch,
+                                                     int sg_nch, int D,
+                                                     int K, int64_t T, double eig_floor,
+                                                     int force_eigh, cplx *__restrict__ Mq,
+                                                     double *__restrict__ logdet,
+                                                     double *__restrict__ pi,
+                                                     int *__restrict__ need_eigh) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NE = tri_count(D);
+    cplx *A = reinterpret_cast<cplx *>(smem);                  // D * (8 NR + 1) + D doubles
+    const int k = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+
+    double sg = 0.0;
+    for (int c = 0; c < sg_nch; ++c) sg += Sg[((int64_t)f * sg_nch + c) * K + k];
+    const double den = fmax(sg, GSS_TINY);
+    if (lane == 0) pi[f * K + k] = sg / (double)T;
+
+    cplx vals[COV_SLOTS];
+    const double tr = reduce_covariance(Bp, nch, D, K, k, f, den, vals, lane);
+    bool fast = !force_eigh && tr > 0.0 && isfinite(tr);
+    if (fast)
+        fast = class_update_chol<NR>(vals, D, K, eig_floor, A, lane, Mq + (int64_t)f * NE * K + k,
+                                     logdet + f * K + k);
+    if (lane == 0) need_eigh[f * K + k] = fast ? 0 : 1;
+}
+
+// Eigendecomposition path for the flagged matrices; overwrites their Mq / ln det.
+__global__ __launch_bounds__(64) void em_eigh_kernel(const cplx *__restrict__ Bp,
+                                                     const double *__restrict__ Sg, int nch,
+                                                     int sg_nch, int D,
+                                                     int K, double eig_floor,
+                                                     const int *__restrict__ need_eigh,
+                                                     cplx *__restrict__ Mq,
+                                                     double *__restrict__ logdet) {
+    const int k = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    if (!need_eigh[f * K + k]) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NE = tri_count(D);
+    double sg = 0.0;
+    for (int c = 0; c < sg_nch; ++c) sg += Sg[((int64_t)f * sg_nch + c) * K + k];
+    const double den = fmax(sg, GSS_TINY);
+    cplx vals[COV_SLOTS];
+    reduce_covariance(Bp, nch, D, K, k, f, den, vals, lane);
+    class_update_eigh(vals, D, K, eig_floor, reinterpret_cast<cplx *>(smem), lane,
+                      Mq + (int64_t)f * NE * K + k, logdet + f * K + k);
 }
 
 size_t em_estep_lds(int D, int K) {

@@ -1,7 +1,7 @@
 // Single-wave dense linear algebra on one small matrix in LDS (leading dimension ld),
 // shared by the CACGMM model update (cacgmm.hip) and the GEV beamformer (mvdr.hip).
-// The calling workgroup is ONE 64-lane wavefront, so __syncthreads() is a
-// single-wave barrier.
+// The caller is ONE 64-lane wavefront (synchronised with wave_sync(), so the wave may
+// be part of a larger workgroup).
 #pragma once
 #include "gss_internal.h"
 
@@ -16,11 +16,11 @@ __device__ inline bool cholesky_lower_wave(cplx *A, int n, int ld, int lane) {
         const double ajj = A[j * ld + j].x;
         if (!(ajj > 0.0) || !isfinite(ajj)) return false;
         const double d = sqrt(ajj), dinv = 1.0 / d;
-        __syncthreads();
+        wave_sync();
         const int i = j + 1 + lane;
         if (i < n) A[i * ld + j] = c_scale(A[i * ld + j], dinv);
         if (lane == 0) A[j * ld + j] = c_make(d, 0.0);
-        __syncthreads();
+        wave_sync();
         // trailing update of the lower triangle: A[i][k] -= L[i][j] conj(L[k][j]), j < k <= i
         const int r = n - j - 1;
         for (int ii = ri; ii < r; ii += 8) {
@@ -34,7 +34,7 @@ __device__ inline bool cholesky_lower_wave(cplx *A, int n, int ld, int lane) {
             }
         }
     }
-    __syncthreads();
+    wave_sync();
     return true;
 }
 
@@ -48,10 +48,10 @@ __device__ inline void invert_lower_wave(cplx *A, int n, int ld, int lane) {
         cplx x = c_make(0.0, 0.0);
         if (i < n)
             for (int k = j + 1; k <= i; ++k) c_fma(x, A[i * ld + k], A[k * ld + j]);
-        __syncthreads();
+        wave_sync();
         if (i < n) A[i * ld + j] = c_make(-ajj * x.x, -ajj * x.y);
         if (lane == 0) A[j * ld + j] = c_make(ajj, 0.0);
-        __syncthreads();
+        wave_sync();
     }
 }
 
@@ -70,7 +70,7 @@ __device__ inline void invert_lower_wave(cplx *A, int n, int ld, int lane) {
 // U[j][k] / dinv[j] for k > j, W[j][k] / dinv[j] for k < j, the pivot a_jj at k = j --
 // and dinv[j] = 1 / U[j][j] (0 where the pivot was not positive and finite); callers
 // scale when they consume.  Returns false (uniformly) if any pivot failed.
-template <int G, int NR>
+template <int G, int NR, bool ONE_WAVE = false>
 __device__ __forceinline__ bool chol_inverse_sweep(cplx (&reg)[NR][NR], int n, cplx *M, int ld,
                                           double *dinv, int tx, int ty) {
     bool ok = true;
@@ -90,7 +90,8 @@ __device__ __forceinline__ bool chol_inverse_sweep(cplx (&reg)[NR][NR], int n, c
 #pragma unroll
             for (int b = 0; b < NR; ++b) M[j * ld + tx + G * b] = pub[b];
         }
-        __syncthreads();
+        if (ONE_WAVE) wave_sync();
+        else __syncthreads();
         // all LDS reads of the step are issued together, unconditionally
         const double ajj = M[j * ld + j].x;
         cplx ru[NR], rv[NR];
@@ -133,6 +134,7 @@ __device__ __forceinline__ bool chol_inverse_sweep(cplx (&reg)[NR][NR], int n, c
                 reg[a][b].y = fma(-u[a].y, vv.x, reg[a][b].y);
             }
     }
-    __syncthreads();
+    if (ONE_WAVE) wave_sync();
+    else __syncthreads();
     return ok;
 }

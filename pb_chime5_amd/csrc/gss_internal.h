@@ -54,6 +54,16 @@ __device__ __forceinline__ void c_cfma(cplx &acc, cplx a, cplx b) {
     acc.y = fma(-a.y, b.x, acc.y);
 }
 
+// Barrier for code that is run by ONE wavefront on data in LDS (the lanes of a wave issue
+// their LDS operations in order, so only the compiler has to be kept from reordering).
+// In a 64-thread workgroup it is equivalent to __syncthreads(); inside a larger
+// workgroup it lets single waves work independently.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -1,6 +1,6 @@
 // Cyclic parallel-order Jacobi eigendecomposition of one complex Hermitian matrix
 // held in LDS, executed by ONE 64-lane wavefront that is the whole workgroup
-// (so __syncthreads() is a single-wave barrier).
+// (synchronised with wave_sync(), so it may also run inside a larger workgroup).
 //
 // Replaces np.linalg.eigh in pb_bss' ComplexAngularCentralGaussian.from_covariance
 // (reached from CACGMMTrainer.fit, reference call site core.py:180-186) and serves
@@ -26,7 +26,7 @@ __device__ inline int jacobi_eigh_wave(cplx *A, cplx *V, int m, int lane, int ma
     const bool active = pr < half;
     for (int i = grp; i < m; i += 4)
         for (int j = pr; j < m; j += 16) V[i * m + j] = c_make(i == j ? 1.0 : 0.0, 0.0);
-    __syncthreads();
+    wave_sync();
     int sweep = 0;
     bool last = false;
     for (; sweep < max_sweeps; ++sweep) {
@@ -99,7 +99,7 @@ __device__ inline int jacobi_eigh_wave(cplx *A, cplx *V, int m, int lane, int ma
                     }
                 }
             }
-            __syncthreads();
+            wave_sync();
             // row update  A <- J^H A   (columns grp, grp + 4, ...)
             if (active) {
                 for (int j = grp; j < m; j += 4) {
@@ -114,7 +114,7 @@ __device__ inline int jacobi_eigh_wave(cplx *A, cplx *V, int m, int lane, int ma
                     A[q * m + j] = nq_;
                 }
             }
-            __syncthreads();
+            wave_sync();
         }
     }
     return sweep;
