@@ -645,59 +645,6 @@ __global__ __launch_bounds__(256) void chol_backsolve_kernel(const cplx *__restr
     chol_backsolve_body(R + (int64_t)f * n * n, P + (int64_t)f * n * D, n, D, S);
 }
 
-// EXPERIMENT (GSS_SOLVE_FUSED=1): the whole solve of one frequency in ONE workgroup
-// (grid (F), block 256), the phases following each other inside the kernel.  One
-// launch instead of 14, but with F = 513 frequencies the chip holds only 2 workgroups
-// (8 waves) per CU and every phase runs at its latency: measured 1.34 ms per solve on
-// MI355X against 0.97 ms for the per-phase kernels below, whose grids are tiles x F.
-// Kept for shapes with many more frequencies than CUs x 3.
-__global__ __launch_bounds__(256, 3) void wpe_solve_fused_kernel(cplx *__restrict__ R,
-                                                              cplx *__restrict__ P, int n,
-                                                              int D) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    cplx *Ud = reinterpret_cast<cplx *>(smem);                       // CH_NB * UD_LD
-    double *dinv = reinterpret_cast<double *>(Ud + CH_NB * UD_LD);   // CH_NB
-    const int f = blockIdx.x, tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    cplx *A = R + (int64_t)f * n * n;
-    cplx *Z = P + (int64_t)f * n * D;
-    const int nblk = (n + CH_NB - 1) / CH_NB;
-
-    for (int J = 0; J < nblk; ++J) {
-        const int j0 = J * CH_NB, nb = min(CH_NB, n - j0);
-        __syncthreads();
-        chol_diag_block(A, n, j0, Ud, dinv);
-        __syncthreads();
-        // ---- row panel on the MFMA, one wave per tile of 16 columns
-        const int ntrail = n - j0 - nb;
-        const int npanel = (ntrail + 15) / 16 + (D + 15) / 16;
-        for (int ct = wave; ct < npanel; ct += 4) chol_panel_tile(A, Z, n, D, j0, nb, ct, Ud, dinv, lane);
-        __syncthreads();
-        // ---- trailing update on 32 x 32 tiles, round robin over the 4 waves
-        const int rs = j0 + nb;
-        const int nt = (n - rs + 31) / 32;
-        const int np = (D + 31) / 32;
-        const int ntiles = nt * (nt + 1) / 2 + nt * np;
-        for (int t = wave; t < ntiles; t += 4) {
-            UpdTile tl;
-            if (t < nt * (nt + 1) / 2) {
-                int a = 0, rem = t;
-                while (rem >= nt - a) {
-                    rem -= nt - a;
-                    ++a;
-                }
-                tl = {rs + 32 * a, rs + 32 * (a + rem), 0, 0};
-            } else {
-                const int u = t - nt * (nt + 1) / 2;
-                tl = {rs + 32 * (u / np), 32 * (u % np), 1, 0};
-            }
-            chol_update_tile<2, 2, true>(A, Z, n, D, j0, nb, tl, lane);
-        }
-    }
-    __syncthreads();
-    chol_backsolve_body(A, Z, n, D, Ud);     // S aliases the (now free) diagonal block
-}
-
 // ------------------------------------------------------------------ apply
 // X[t][d] = Y[t][d] - sum_r conj(G[r][d]) Yflat[(t - c) D + r]
 // As a GEMM per frequency: out(frames x channels) = U conj(G), K = n = taps * D, on the
@@ -896,15 +843,12 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
 
     // tile lists: correlation tiles, then one trailing-update list per block column
     std::vector<CorrTile> tiles;
-    int corr_ts = 2;
-    if (const char *e = getenv("GSS_CORR_TS")) corr_ts = atoi(e) == 3 ? 3 : 2;
+    constexpr int corr_ts = 2;       // 32 x 32 wave tiles (48 x 48 measured slower)
     const int ntiles = corr_tiles(n, D, c, 16 * corr_ts, tiles);
-    // trailing-update tiles: (16 TM) x (16 TN), every tile that reaches the upper triangle
-    int upd_variant = 0;
-    if (const char *e = getenv("GSS_UPD_VARIANT")) upd_variant = atoi(e);
-    else upd_variant = 6;
-    static const int UPD_TM[] = {3, 3, 2, 2, 2, 1, 1, 2}, UPD_TN[] = {3, 3, 3, 2, 2, 2, 1, 4};
-    const int tm16 = 16 * UPD_TM[upd_variant & 7], tn16 = 16 * UPD_TN[upd_variant & 7];
+    // trailing-update tiles: 16 x 16, every tile that reaches the upper triangle (larger
+    // register tiles -- 2 x 2, 2 x 3, 3 x 3 MFMA tiles per wave -- measured slower: the
+    // update is bound by its traffic and wants many small workgroups in flight)
+    constexpr int tm16 = 16, tn16 = 16;
     std::vector<UpdTile> upd;
     std::vector<int> upd_start, upd_count;
     {
@@ -924,7 +868,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                 "wpe: taps*D=%d too large", n);
     static_assert(sizeof(CorrTile) == sizeof(UpdTile), "tile structs share one buffer");
     if (ctx->wpe_tiles_key[0] != taps || ctx->wpe_tiles_key[1] != delay ||
-        ctx->wpe_tiles_key[2] != D + 1000 * upd_variant + 100000 * corr_ts) {
+        ctx->wpe_tiles_key[2] != D) {
         GSS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (!ctx->wpe_tiles)
             GSS_HIP_CHECK(ctx, hipMalloc(&ctx->wpe_tiles, sizeof(CorrTile) * (1024 + 4096)));
@@ -936,7 +880,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                                          hipMemcpyHostToDevice));
         ctx->wpe_tiles_key[0] = taps;
         ctx->wpe_tiles_key[1] = delay;
-        ctx->wpe_tiles_key[2] = D + 1000 * upd_variant + 100000 * corr_ts;
+        ctx->wpe_tiles_key[2] = D;
     }
     CorrTile *tiles_dev = reinterpret_cast<CorrTile *>(ctx->wpe_tiles);
     UpdTile *upd_dev = reinterpret_cast<UpdTile *>(tiles_dev + 1024);
@@ -945,17 +889,12 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     // 3 real MFMAs per complex product (t1 = ar br, t2 = ai bi, t3 = (ar + ai)(br - bi));
     // GSS_CORR_4M=1 selects the 4-product form
     const bool corr_3m = getenv("GSS_CORR_4M") == nullptr;
-    auto corr_fn = corr_ts == 2 ? (corr_3m ? wpe_corr_kernel<2, true> : wpe_corr_kernel<2, false>)
-                                : (corr_3m ? wpe_corr_kernel<3, true> : wpe_corr_kernel<3, false>);
+    auto corr_fn = corr_3m ? wpe_corr_kernel<corr_ts, true> : wpe_corr_kernel<corr_ts, false>;
     const size_t corr_lds = sizeof(cplx) * (size_t)(CORR_KT + c + padf) * D + sizeof(double) * CORR_KT;
     const size_t panel_lds = sizeof(cplx) * CH_NB * UD_LD + sizeof(double) * CH_NB;
-    const size_t fused_lds = panel_lds;
     static_assert(BS_LD <= UD_LD, "S must fit in Ud");
-    const bool solve_fused = getenv("GSS_SOLVE_FUSED") != nullptr;
-    static const int apply_ta = getenv("GSS_APPLY_TA") ? atoi(getenv("GSS_APPLY_TA")) : 2;
-    const int apply_frames = apply_ta == 2 ? 128 : 64;
-    auto apply_fn = D <= 16 ? (apply_ta == 2 ? wpe_apply_kernel<2, 1> : wpe_apply_kernel<1, 1>)
-                            : (apply_ta == 2 ? wpe_apply_kernel<2, 2> : wpe_apply_kernel<1, 2>);
+    constexpr int apply_ta = 2, apply_frames = 64 * apply_ta;
+    auto apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1> : wpe_apply_kernel<apply_ta, 2>;
     const size_t apply_lds = sizeof(cplx) * (size_t)(apply_frames + c + 2) * (D | 1);
     GSS_REQUIRE(ctx, corr_lds <= 160 * 1024 && apply_lds <= 160 * 1024, GSS_ERR_UNSUPPORTED,
                 "wpe: taps=%d D=%d needs more LDS than a CU has", taps, D);
@@ -981,12 +920,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                                ctx->stream, Y, w, F, T, D, n, c, padf, tiles_dev, ntiles, R, P);
             GSS_LAUNCH_CHECK(ctx, "wpe_corr_kernel");
         }
-        if (solve_fused) {
-            GSS_PROF(ctx, "wpe_solve");
-            hipLaunchKernelGGL(wpe_solve_fused_kernel, dim3(F), dim3(256), fused_lds, ctx->stream,
-                               R, P, n, D);
-            GSS_LAUNCH_CHECK(ctx, "wpe_solve_fused_kernel");
-        } else {
+        {
             const int nblk = (n + CH_NB - 1) / CH_NB;
             for (int J = 0; J < nblk; ++J) {
                 const int j0 = J * CH_NB, nb = std::min(CH_NB, n - j0);
@@ -1008,40 +942,8 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                     GSS_PROF(ctx, "wpe_chol_update");
                     const dim3 g((nupd + 3) / 4, F), b(256);
                     const UpdTile *tl = upd_dev + upd_start[J];
-                    switch (upd_variant & 7) {
-                        case 0:
-                            hipLaunchKernelGGL((chol_update_kernel<3, 3, true>), g, b, 0, ctx->stream,
-                                               R, P, n, D, j0, nb, tl, nupd);
-                            break;
-                        case 1:
-                            hipLaunchKernelGGL((chol_update_kernel<3, 3, false>), g, b, 0, ctx->stream,
-                                               R, P, n, D, j0, nb, tl, nupd);
-                            break;
-                        case 2:
-                            hipLaunchKernelGGL((chol_update_kernel<2, 3, true>), g, b, 0, ctx->stream,
-                                               R, P, n, D, j0, nb, tl, nupd);
-                            break;
-                        case 3:
-                            hipLaunchKernelGGL((chol_update_kernel<2, 2, true>), g, b, 0, ctx->stream,
-                                               R, P, n, D, j0, nb, tl, nupd);
-                            break;
-                        case 4:
-                            hipLaunchKernelGGL((chol_update_kernel<2, 2, false>), g, b, 0, ctx->stream,
-                                               R, P, n, D, j0, nb, tl, nupd);
-                            break;
-                        case 5:
-                            hipLaunchKernelGGL((chol_update_kernel<1, 2, true>), g, b, 0, ctx->stream,
-                                               R, P, n, D, j0, nb, tl, nupd);
-                            break;
-                        case 6:
-                            hipLaunchKernelGGL((chol_update_kernel<1, 1, true>), g, b, 0, ctx->stream,
-                                               R, P, n, D, j0, nb, tl, nupd);
-                            break;
-                        default:
-                            hipLaunchKernelGGL((chol_update_kernel<2, 4, true>), g, b, 0, ctx->stream,
-                                               R, P, n, D, j0, nb, tl, nupd);
-                            break;
-                    }
+                    hipLaunchKernelGGL((chol_update_kernel<1, 1, true>), g, b, 0, ctx->stream, R, P,
+                                       n, D, j0, nb, tl, nupd);
                     GSS_LAUNCH_CHECK(ctx, "chol_update_kernel");
                 }
             }

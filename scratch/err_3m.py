@@ -1,5 +1,5 @@
 """Relative error of the enhanced signal against the oracle, 4M vs 3M correlation.
-Run with GSS_CORR_3M unset / set."""
+Run with GSS_CORR_4M unset (3-product form, default) / set (4-product form)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, 'oracle'); sys.path.insert(0, '.')
@@ -18,4 +18,4 @@ x_ref = oracle.enhance_observation(utt.obs, utt.activity_array, utt.target_index
                                    wpe_delay=2, wpe_iterations=3, bss_iterations=20, bss_iterations_post=1)
 print('oracle s', round(time.time() - t, 1))
 e = np.linalg.norm(x_gpu - x_ref) / np.linalg.norm(x_ref)
-print('3M' if os.environ.get('GSS_CORR_3M') else '4M', 'rel err', e)
+print('4M' if os.environ.get('GSS_CORR_4M') else '3M', 'rel err', e)
