@@ -53,7 +53,7 @@ def _rir(rng, taps=2048):
 
 
 def make_utterance(seed, num_channels, num_samples, intervals, target=0,
-                   start_context=0, end_context=0, rir_taps=2048):
+                   start_context=0, end_context=0, rir_taps=2048, noise=1e-3):
     """intervals: list of (start, stop) sample pairs, one per speaker; the
     ``Noise`` class is appended as all-True.  ``start_context``/``end_context``
     are the context samples on each side of the core segment."""
@@ -69,7 +69,7 @@ def make_utterance(seed, num_channels, num_samples, intervals, target=0,
         for d in range(num_channels):
             obs[d] += fftconvolve(src, _rir(rng, rir_taps))[:num_samples]
     activity['Noise'] = np.ones(num_samples, dtype=bool)
-    obs += rng.standard_normal(obs.shape) * 1e-3
+    obs += rng.standard_normal(obs.shape) * noise
     obs *= 0.1
     speaker_id = f'P{target + 1:02d}'
     ex = {
@@ -126,9 +126,16 @@ def config3_item(index, num_channels=24, context=240000):
         length = int(rng.uniform(0.3, 0.6) * n)
         a = int(rng.integers(0, n - length))
         intervals.append((a, a + length))
+    # CHiME-5 is a dinner party: somebody else talks over the target.  One interferer is
+    # moved so that it covers part of the core (otherwise the distortion mask is empty
+    # inside the only frames the beamformer looks at and its PSD matrix has rank 1), and
+    # the sensor noise sits 30 dB below the speech instead of 60 dB.
+    length = intervals[1][1] - intervals[1][0]
+    a = int(np.clip(context + core // 2 - length // 2 + rng.integers(-sr, sr + 1), 0, n - length))
+    intervals[1] = (a, a + length)
     return make_utterance(seed, num_channels, n, intervals, target=0,
                           start_context=context, end_context=context,
-                          rir_taps=1024)
+                          rir_taps=1024, noise=3e-2)
 
 
 def config5(seed=5, num_channels=12, seconds=120.0):

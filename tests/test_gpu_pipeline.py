@@ -255,6 +255,90 @@ def test_config2_stagewise_vs_oracle_on_frequency_subset(gpu_ctx, config2_run):
     assert rel_err(x_hat, oracle.istft(det['X_hat'])) < 1e-11
 
 
+def _stagewise(gpu_ctx, u, bins, *, bf='mvdrSouden_ban', bss_iterations=20, tol_wpe=1e-6):
+    """GPU pipeline on utterance u, every stage checked against the oracle fed with the GPU's
+    own upstream tensors (WPE and EM on the frequency subset `bins`, the rest on all bins)."""
+    from pb_chime5_amd import ops
+    cs = u.ex['start_orig']['original']
+    ce = u.ex['end']['original'] - u.ex['end_orig']['original']
+    x_hat, det = ops.enhance_observation(u.obs, u.activity_array, u.target_index, cs, ce,
+                                         debug=True, ctx=gpu_ctx, bf=bf,
+                                         bss_iterations=bss_iterations)
+    D, T = u.obs.shape[0], det['Obs'].shape[1]
+    assert det['Obs'].shape == (D, T, 513)
+    Y = oracle.stft(u.obs)[..., bins]
+    assert rel_err(det['Obs'][..., bins], oracle.wpe_block(Y, 10, 2, 3)) < tol_wpe
+    act_f = oracle.activity_time_to_frequency(u.activity_array, 1024, 256, True)
+    assert np.array_equal(det['acitivity_freq'], act_f[:, :T])
+    post_want = oracle.gss_block(det['Obs'][..., bins], act_f[:, :T], bss_iterations, 1)
+    assert np.max(np.abs(det['posterior'][..., bins] - post_want)) < 1e-5
+    masks = det['posterior'].copy()
+    sf, ef = oracle.start_end_context_frames(u.ex, 1024, 256, True)
+    masks[:, :sf] = 0
+    if ef > 0:
+        masks[:, -ef:] = 0
+    tm = masks[u.target_index]
+    dm = np.sum(np.delete(masks, u.target_index, axis=0), axis=0)
+    assert np.array_equal(det['target_mask'], tm)
+    # Beamformer on all bins.  The synthetic sources separate so cleanly that at many bins a
+    # few frames carry the whole distortion mask and Phi_N is nearly singular.  There the
+    # reference's own arithmetic is the limit: blind_analytic_normalization evaluates
+    # w^H Phi_N Phi_N w as one four-operand einsum, which cancels catastrophically once
+    # cond(Phi_N)^2 eps > 1 (measured against an 80-bit evaluation: the literal formula is
+    # off by 14 % at cond 5e9, the GPU, which forms ||Phi_N w||, by 3e-8 --
+    # scratch/cfg3_debug.py).  So: the literal oracle is the yardstick where
+    # cond(Phi_N) < 1e8, the same formula evaluated as ||Phi_N w|| / |w^H Phi_N w| up to
+    # cond 1e10, and the reference channel (a cross-frequency sum that the ill-conditioned
+    # bins dominate) is handed over from the GPU unless the SNRs are sane.
+    Yf = det['Obs'].transpose(2, 0, 1)
+    cov_x = oracle.get_power_spectral_density_matrix(Yf, tm.T)
+    cov_n = oracle.get_power_spectral_density_matrix(Yf, dm.T)
+    cond = np.linalg.cond(cov_n)
+    strict, good = cond < 1e8, cond < 1e10
+    assert good.mean() > 0.3, good.mean()
+    if bf == 'gev_ban':
+        X_want = oracle.beamform_gev_from_masks(det['Obs'], tm, dm, ban=True)
+        assert rel_err(np.abs(det['X_hat'][:, strict]), np.abs(X_want[:, strict])) < TOL_STFT_MAG
+    else:
+        phi = oracle.stable_solve(cov_n, cov_x)
+        mat = phi / np.maximum(np.trace(phi, axis1=-1, axis2=-2)[..., None, None].real, 1e-10)
+        num = np.einsum('FdR,FdD,FDR->R', mat.conj(), cov_x, mat).real
+        den = np.einsum('FdR,FdD,FDR->R', mat.conj(), cov_n, mat).real
+        snr = num / np.maximum(den, 1e-10)
+        if snr.max() < 1e12:
+            assert det['ref_channel'] == int(np.argmax(snr))
+        w = oracle.get_mvdr_vector_souden(cov_x, cov_n, ref_channel=det['ref_channel'], eps=1e-10)
+        w_lit = oracle.blind_analytic_normalization(w, cov_n)
+        X_lit = oracle.apply_beamforming_vector(w_lit, Yf).T
+        if strict.any():
+            assert rel_err(np.abs(det['X_hat'][:, strict]), np.abs(X_lit[:, strict])) < TOL_STFT_MAG
+        pw = np.einsum('fab,fb->fa', cov_n, w)
+        scale = np.linalg.norm(pw, axis=-1) / np.abs(np.einsum('fa,fa->f', w.conj(), pw))
+        X_want = oracle.apply_beamforming_vector(w * scale[:, None], Yf).T
+        assert rel_err(np.abs(det['X_hat'][:, good]), np.abs(X_want[:, good])) < TOL_STFT_MAG
+    assert rel_err(x_hat, oracle.istft(det['X_hat'])) < 1e-11
+    assert np.all(np.isfinite(x_hat))
+    return x_hat, det
+
+
+def test_config3_dev_shaped_utterance_stagewise(gpu_ctx):
+    """BASELINE.json configs[2]: a dev-shaped utterance (24 ch, reference-default context of
+    240000 samples on both sides -> about 2000 frames), checked stage by stage."""
+    from pb_chime5_amd import synthetic
+    u = synthetic.config3_item(0)
+    x_hat, det = _stagewise(gpu_ctx, u, [7, 200, 480])
+    assert det['Obs'].shape[1] > 1900
+
+
+def test_config5_long_rttm_segment_gev_stagewise(gpu_ctx):
+    """BASELINE.json configs[4]: 120 s, 12 channels ('outer_array_mics'), 40 EM iterations,
+    GEV + BAN beamformer (T = 7503 frames: the STFT tensor alone is 740 MB)."""
+    from pb_chime5_amd import synthetic
+    u = synthetic.config5()
+    x_hat, det = _stagewise(gpu_ctx, u, [33, 400], bf='gev_ban', bss_iterations=40)
+    assert det['Obs'].shape[:2] == (12, 7503)
+
+
 def test_config2_end_to_end_vs_oracle(gpu_ctx, config2_run):
     """The bench workload (BASELINE.json configs[1]) end to end against the oracle run on
     ALL 513 bins (about 90 s of CPU).  Measured: 3e-8 after WPE, 1e-5 on the enhanced
