@@ -220,6 +220,18 @@ int gss_enhance_observation(gss_ctx *ctx, const gss_params *params,
                             int64_t end_context_samples,
                             double *out_dev, const gss_debug_taps *taps);
 
+/* Same pipeline fed with the 16-bit PCM samples as they sit in the WAV files: the
+ * conversion of the reference's loader, float64(sample) / 2^15 (io/audioread.py:34-226 via
+ * soundfile), happens inside the STFT kernel -- bit-identical, a quarter of the H2D bytes and
+ * no float64 copy of the recording on the host. */
+int gss_enhance_observation_pcm16(gss_ctx *ctx, const gss_params *params,
+                                  const int16_t *obs_dev, int D, int64_t N,
+                                  const uint8_t *act_dev, int K, int64_t N_act,
+                                  int target_index,
+                                  int64_t start_context_samples,
+                                  int64_t end_context_samples,
+                                  double *out_dev, const gss_debug_taps *taps);
+
 /* Same, with host buffers: copies in, runs, copies out, synchronises. */
 int gss_enhance_observation_host(gss_ctx *ctx, const gss_params *params,
                                  const double *obs_host, int D, int64_t N,

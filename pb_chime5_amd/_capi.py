@@ -84,6 +84,10 @@ SIGNATURES = {
         c_int, [c_void_p, ctypes.POINTER(GssParams), c_void_p, c_int, c_int64,
                 c_void_p, c_int, c_int64, c_int, c_int64, c_int64, c_void_p,
                 ctypes.POINTER(GssDebugTaps)]),
+    'gss_enhance_observation_pcm16': (
+        c_int, [c_void_p, ctypes.POINTER(GssParams), c_void_p, c_int, c_int64,
+                c_void_p, c_int, c_int64, c_int, c_int64, c_int64, c_void_p,
+                ctypes.POINTER(GssDebugTaps)]),
     'gss_enhance_observation_host': (
         c_int, [c_void_p, ctypes.POINTER(GssParams), c_void_p, c_int, c_int64,
                 c_void_p, c_int, c_int64, c_int, c_int64, c_int64, c_void_p]),

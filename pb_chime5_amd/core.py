@@ -284,26 +284,52 @@ class Enhancer:
                     raise
             return
         pipe = ops.UtterancePipeline(self._params(), depth=self.inflight, first_ctx=self._ctx())
-        try:
-            for ex in examples:
+        # A loader thread reads the audio of the next examples while this thread feeds the
+        # GPU and writes results (file reads and NumPy copies release the GIL).  The samples
+        # stay 16-bit PCM on the host; the STFT kernel converts them.
+        from concurrent.futures import ThreadPoolExecutor
+        from collections import deque
+
+        def prepare(ex):
+            obs, ex_array_activity, speaker_id = self._prepare_example(ex, dtype=np.int16)
+            target = tuple(ex_array_activity.keys()).index(speaker_id)
+            activity = np.array(list(ex_array_activity.values()))
+            start_ctx = end_ctx = 0
+            if self.bf_drop_context:
+                start_ctx, end_ctx = start_end_context_samples(ex)
+            return obs, activity, target, start_ctx, end_ctx
+
+        loader = ThreadPoolExecutor(max_workers=1)
+        ahead = deque()
+        source = iter(examples)
+
+        def refill():
+            while len(ahead) < self.inflight:
                 try:
-                    obs, ex_array_activity, speaker_id = self._prepare_example(ex)
-                    target = tuple(ex_array_activity.keys()).index(speaker_id)
-                    activity = np.array(list(ex_array_activity.values()))
-                    start_ctx = end_ctx = 0
-                    if self.bf_drop_context:
-                        start_ctx, end_ctx = start_end_context_samples(ex)
-                    if pipe.full():
-                        done, x_hat = pipe.pop()
-                        self._write(done, self._trim_context(x_hat, done), audio_dir)
-                    pipe.enqueue(ex, obs, activity, target, start_ctx, end_ctx)
+                    ex = next(source)
+                except StopIteration:
+                    return
+                ahead.append((ex, loader.submit(prepare, ex)))
+
+        try:
+            refill()
+            while ahead:
+                ex, future = ahead.popleft()
+                try:
+                    prepared = future.result()
                 except Exception:
                     print('ERROR: Failed example:', ex.get('example_id'))
                     raise
+                refill()
+                if pipe.full():
+                    done, x_hat = pipe.pop()
+                    self._write(done, self._trim_context(x_hat, done), audio_dir)
+                pipe.enqueue(ex, *prepared)
             while len(pipe):
                 done, x_hat = pipe.pop()
                 self._write(done, self._trim_context(x_hat, done), audio_dir)
         finally:
+            loader.shutdown(wait=True, cancel_futures=True)
             pipe.close()
 
     # ------------------------------------------------------------------ examples
@@ -336,9 +362,10 @@ class Enhancer:
                     'projection of the human annotations.') from None
         return reference_array
 
-    def _prepare_example(self, ex):
+    def _prepare_example(self, ex, dtype=np.float64):
         """Host side of enhance_example (core.py:396-490): activity slices of the
-        reference array, channel selection, arrays cut to the shortest."""
+        reference array, channel selection, arrays cut to the shortest.  ``dtype=np.int16``
+        keeps the PCM samples as stored (the session driver converts on the device)."""
         session_id = ex['session_id']
         reference_array = self._reference_array(ex)
         speaker_id = ex['speaker_id']
@@ -354,7 +381,7 @@ class Enhancer:
             arrays = [
                 load_audio(ex['audio_path']['observation'][array],
                            start=ex['start']['observation'][array],
-                           stop=ex['end']['observation'][array])
+                           stop=ex['end']['observation'][array], dtype=dtype)
                 for array in sorted(ex['audio_path']['observation'].keys())
             ]
             # The context does not consider the end of an utterance: arrays can
@@ -373,7 +400,7 @@ class Enhancer:
         elif self.multiarray is False:
             obs = load_audio(ex['audio_path']['observation'][reference_array],
                              start=ex['start']['observation'][reference_array],
-                             stop=ex['end']['observation'][reference_array])
+                             stop=ex['end']['observation'][reference_array], dtype=dtype)
         else:
             raise ValueError(self.multiarray)
         return obs, ex_array_activity, speaker_id

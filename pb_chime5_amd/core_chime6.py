@@ -60,7 +60,7 @@ class Enhancer(core.Enhancer):
             drop_unknown_target_speaker=True, context_samples=self.context_samples,
             equal_start_context=False)
 
-    def _prepare_example(self, ex):
+    def _prepare_example(self, ex, dtype=np.float64):
         """Host side of core_chime6.py:396-487: one clock for activity and all arrays."""
         session_id = ex['session_id']
         speaker_id = ex['speaker_id']
@@ -72,7 +72,7 @@ class Enhancer(core.Enhancer):
 
         def load_arrays(select):
             arrays = [load_audio(ex['audio_path']['observation'][array], start=array_start,
-                                 stop=array_end)
+                                 stop=array_end, dtype=dtype)
                       for array in sorted(ex['audio_path']['observation'].keys())]
             assert {v.ndim for v in arrays} == {2}, [v.shape for v in arrays]
             time_length = min(v.shape[-1] for v in arrays)
@@ -87,7 +87,7 @@ class Enhancer(core.Enhancer):
             obs = load_arrays(lambda v: v[(0,), :])
         elif self.multiarray is False:
             obs = load_audio(ex['audio_path']['observation'][self._reference_array(ex)],
-                             start=array_start, stop=array_end)
+                             start=array_start, stop=array_end, dtype=dtype)
         else:
             raise ValueError(self.multiarray)
         return obs, ex_array_activity, speaker_id

@@ -11,6 +11,8 @@ RTTM activity in the window guides the CACGMM.  Arrays are already synchronised 
 CHiME-6, so start / end are plain integers (``core_chime6.py:214-216``).
 """
 from dataclasses import dataclass, field
+
+import numpy as np
 from pathlib import Path
 
 from pb_chime5_amd import core, mapping
@@ -74,15 +76,22 @@ class Enhancer(core.Enhancer):
         # hand out indices, not loaded examples: audio is read by the rank that works
         costs = [ex['num_samples'] for ex in it.examples]
         indices = parallel.split_managed(range(len(it)), costs=costs)
-        self._enhance_and_write((it[index] for index in indices), audio_dir)
+        # the examples travel without audio; _prepare_example reads it (on the loader thread)
+        self._enhance_and_write((dict(it.examples[index]) for index in indices), audio_dir)
 
-    def _prepare_example(self, ex):
-        """core_chime6_rttm.py:228-258: the audio came with the example."""
+    def _prepare_example(self, ex, dtype=np.float64):
+        """core_chime6_rttm.py:228-258.  Examples of ``get_dataset`` carry their audio;
+        inside ``enhance_session`` it is read here (``dtype=np.int16``: PCM as stored)."""
         array_start, array_end = ex['start'], ex['end']
         ex_array_activity = {
             k: arr[array_start:array_end] for k, arr in self.activity[ex['session_id']].items()
         }
-        return ex['audio_data'], ex_array_activity, ex['speaker_id']
+        obs = ex.get('audio_data')
+        if obs is None:
+            obs = rttm_module.recursive_load_audio(
+                ex['audio_path'], start=array_start, stop=array_end,
+                min_num_samples=ex.get('end_orig', array_end) - array_start, dtype=dtype)
+        return obs, ex_array_activity, ex['speaker_id']
 
     def _trim_context(self, x_hat, ex):
         if self.context_samples > 0:

@@ -330,7 +330,7 @@ extern "C" int gss_stft(gss_ctx *ctx, const double *x, int D, int64_t N, int fad
     GSS_ENTER(ctx);
     GSS_TRY(check_windows(ctx));
     GSS_REQUIRE(ctx, D >= 1 && N >= 0 && x && Y, GSS_ERR_INVALID, "gss_stft: bad arguments");
-    return stft_run(ctx, x, D, N, fading, reinterpret_cast<cplx *>(Y));
+    return stft_run(ctx, x, 0, D, N, fading, reinterpret_cast<cplx *>(Y));
 }
 
 extern "C" int gss_istft(gss_ctx *ctx, const gss_cplx *X, int64_t T, int fading, double *x) {
@@ -455,12 +455,10 @@ static size_t pipeline_workspace(const gss_params *p, int F, int64_t T, int64_t 
     return b + stage + (1 << 16);
 }
 
-extern "C" int gss_enhance_observation(gss_ctx *ctx, const gss_params *p, const double *obs,
-                                       int D, int64_t N, const uint8_t *act, int K,
-                                       int64_t N_act, int target, int64_t start_ctx,
-                                       int64_t end_ctx, double *out,
-                                       const gss_debug_taps *taps) {
-    GSS_ENTER(ctx);
+static int enhance_observation_impl(gss_ctx *ctx, const gss_params *p, const void *obs,
+                                    int obs_type, int D, int64_t N, const uint8_t *act, int K,
+                                    int64_t N_act, int target, int64_t start_ctx, int64_t end_ctx,
+                                    double *out, const gss_debug_taps *taps) {
     GSS_TRY(check_windows(ctx));
     GSS_TRY(check_params(ctx, p));
     GSS_REQUIRE(ctx, obs && act && out && N >= 1, GSS_ERR_INVALID,
@@ -501,7 +499,7 @@ extern "C" int gss_enhance_observation(gss_ctx *ctx, const gss_params *p, const 
                 "workspace sizing bug");
     const size_t mark = ctx->arena_off;
 
-    GSS_TRY(stft_run(ctx, obs, D, N, fading, Y));
+    GSS_TRY(stft_run(ctx, obs, obs_type, D, N, fading, Y));
     if (p->wpe) {
         GSS_TRY(wpe_run(ctx, Y, F, T, D, p->wpe_taps, p->wpe_delay, p->wpe_iterations, X));
         ctx->arena_off = mark;
@@ -546,6 +544,26 @@ extern "C" int gss_enhance_observation(gss_ctx *ctx, const gss_params *p, const 
         if (p->bf == 0 || p->bf == 3) GSS_TRY(cp(taps->ref_channel, ref, sizeof(int32_t)));
     }
     return GSS_OK;
+}
+
+extern "C" int gss_enhance_observation(gss_ctx *ctx, const gss_params *p, const double *obs,
+                                       int D, int64_t N, const uint8_t *act, int K,
+                                       int64_t N_act, int target, int64_t start_ctx,
+                                       int64_t end_ctx, double *out,
+                                       const gss_debug_taps *taps) {
+    GSS_ENTER(ctx);
+    return enhance_observation_impl(ctx, p, obs, 0, D, N, act, K, N_act, target, start_ctx, end_ctx,
+                                    out, taps);
+}
+
+extern "C" int gss_enhance_observation_pcm16(gss_ctx *ctx, const gss_params *p,
+                                             const int16_t *obs, int D, int64_t N,
+                                             const uint8_t *act, int K, int64_t N_act, int target,
+                                             int64_t start_ctx, int64_t end_ctx, double *out,
+                                             const gss_debug_taps *taps) {
+    GSS_ENTER(ctx);
+    return enhance_observation_impl(ctx, p, obs, 1, D, N, act, K, N_act, target, start_ctx, end_ctx,
+                                    out, taps);
 }
 
 extern "C" int gss_enhance_observation_host(gss_ctx *ctx, const gss_params *p,

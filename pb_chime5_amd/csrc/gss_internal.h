@@ -204,7 +204,7 @@ int masks_from_posteriors_run(gss_ctx *ctx, const double *gamma, int F, int K, i
                               int64_t end_frames, double *mx, double *mn);
 
 size_t stft_workspace_bytes(int64_t T, int size);
-int stft_run(gss_ctx *ctx, const double *x, int D, int64_t N, int fading, cplx *Y);
+int stft_run(gss_ctx *ctx, const void *x, int in_type, int D, int64_t N, int fading, cplx *Y);
 int istft_run(gss_ctx *ctx, const cplx *X, int64_t T, int fading, double *x);
 int activity_run(gss_ctx *ctx, const uint8_t *act, int K, int64_t N, int fading,
                  uint8_t *out);

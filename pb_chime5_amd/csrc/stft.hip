@@ -45,9 +45,11 @@ __device__ void fft_lds(cplx *s, int n, int log2n, int nseq, const cplx *tw, boo
 
 // grid: (T, ceil(D / (2*PAIRS))); one workgroup transforms up to 2*PAIRS channels
 // of one frame.
-template <int PAIRS>
+// TIn: double (the reference's float64 samples) or int16_t (PCM as it sits in the WAV file;
+// multiplied by in_scale = 2^-15, which is exactly what the reference's loader does).
+template <int PAIRS, typename TIn>
 __global__ __launch_bounds__(FFT_THREADS) void stft_kernel(
-    const double *__restrict__ x, int D, int64_t N, int64_t T, int size, int log2n, int shift,
+    const TIn *__restrict__ x, double in_scale, int D, int64_t N, int64_t T, int size, int log2n, int shift,
     int pad, const double *__restrict__ window, const cplx *__restrict__ twiddle,
     cplx *__restrict__ Y) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -71,8 +73,8 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_kernel(
         double va = 0.0, vb = 0.0;
         if (n >= 0 && n < N) {
             const double w = window[i];
-            if (da < D) va = x[(int64_t)da * N + n] * w;
-            if (db < D) vb = x[(int64_t)db * N + n] * w;
+            if (da < D) va = ((double)x[(int64_t)da * N + n] * in_scale) * w;
+            if (db < D) vb = ((double)x[(int64_t)db * N + n] * in_scale) * w;
         }
         s[pr * size + bitrev(i, log2n)] = c_make(va, vb);
         if (va != 0.0) mine |= 1u << (2 * pr);
@@ -273,25 +275,34 @@ size_t stft_workspace_bytes(int64_t T, int size) {
     return align_up(sizeof(double) * (size_t)(T + 1) * size) + 4096;
 }
 
-int stft_run(gss_ctx *ctx, const double *x, int D, int64_t N, int fading, cplx *Y) {
+template <int PAIRS, typename TIn>
+static void stft_launch(gss_ctx *ctx, const TIn *x, double in_scale, int D, int64_t N, int64_t T,
+                        int size, int shift, int pad, cplx *Y) {
+    dim3 grid((unsigned)T, (D + 2 * PAIRS - 1) / (2 * PAIRS));
+    const size_t lds = sizeof(cplx) * (PAIRS * size + size / 2) + 16;
+    hipLaunchKernelGGL((stft_kernel<PAIRS, TIn>), grid, dim3(FFT_THREADS), lds, ctx->stream, x,
+                       in_scale, D, N, T, size, ilog2(size), shift, pad, ctx->win_analysis,
+                       ctx->twiddle, Y);
+}
+
+// x: (D, N) samples, double (in_type 0) or int16 PCM scaled by 2^-15 (in_type 1)
+int stft_run(gss_ctx *ctx, const void *x, int in_type, int D, int64_t N, int fading, cplx *Y) {
     const int size = ctx->stft_size, shift = ctx->stft_shift;
     const int64_t T = gss_stft_num_frames(N, size, shift, fading);
     const int pad = fading ? size - shift : 0;
     GSS_REQUIRE(ctx, T < 2147483647, GSS_ERR_UNSUPPORTED, "too many frames");
+    GSS_REQUIRE(ctx, in_type == 0 || in_type == 1, GSS_ERR_INVALID, "sample type %d", in_type);
     GSS_PROF(ctx, "stft");
+    const double *xd = static_cast<const double *>(x);
+    const int16_t *xi = static_cast<const int16_t *>(x);
+    const double pcm = 1.0 / 32768.0;
     // 4 pairs (8 channels) per workgroup while that fits comfortably in LDS
     if (size <= 1024) {
-        constexpr int PAIRS = 4;
-        dim3 grid((unsigned)T, (D + 2 * PAIRS - 1) / (2 * PAIRS));
-        size_t lds = sizeof(cplx) * (PAIRS * size + size / 2) + 16;
-        hipLaunchKernelGGL(stft_kernel<PAIRS>, grid, dim3(FFT_THREADS), lds, ctx->stream, x, D, N,
-                           T, size, ilog2(size), shift, pad, ctx->win_analysis, ctx->twiddle, Y);
+        if (in_type == 0) stft_launch<4>(ctx, xd, 1.0, D, N, T, size, shift, pad, Y);
+        else stft_launch<4>(ctx, xi, pcm, D, N, T, size, shift, pad, Y);
     } else {
-        constexpr int PAIRS = 1;
-        dim3 grid((unsigned)T, (D + 1) / 2);
-        size_t lds = sizeof(cplx) * (PAIRS * size + size / 2) + 16;
-        hipLaunchKernelGGL(stft_kernel<PAIRS>, grid, dim3(FFT_THREADS), lds, ctx->stream, x, D, N,
-                           T, size, ilog2(size), shift, pad, ctx->win_analysis, ctx->twiddle, Y);
+        if (in_type == 0) stft_launch<1>(ctx, xd, 1.0, D, N, T, size, shift, pad, Y);
+        else stft_launch<1>(ctx, xi, pcm, D, N, T, size, shift, pad, Y);
     }
     GSS_LAUNCH_CHECK(ctx, "stft_kernel");
     return GSS_OK;

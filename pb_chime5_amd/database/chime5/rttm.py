@@ -116,10 +116,10 @@ def select_channels(chime6_dir, multiarray):
     raise ValueError(multiarray)
 
 
-def recursive_load_audio(paths, start=0, stop=None, min_num_samples=1):
+def recursive_load_audio(paths, start=0, stop=None, min_num_samples=1, dtype=np.float64):
     """Load every channel file, drop the ones that end before the segment ("last 15
     minutes of U05 missing"), cut the rest to the shortest (rttm.py:550-632)."""
-    data = [load_audio(p, start=start, stop=stop) for p in paths]
+    data = [load_audio(p, start=start, stop=stop, dtype=dtype) for p in paths]
     kept = [d for d in data if d.shape[-1] >= min_num_samples]
     assert len(kept) >= len(data) - 8, (len(kept), len(data))
     num_samples = min(d.shape[-1] for d in kept)
@@ -192,20 +192,21 @@ class RTTMDatabase:
 class LazyAudio:
     """Sequence of examples whose ``audio_data`` is read when an item is accessed."""
 
-    def __init__(self, examples):
+    def __init__(self, examples, dtype=np.float64):
         self.examples = examples
+        self.dtype = dtype       # np.int16: PCM as stored (converted on the device)
 
     def __len__(self):
         return len(self.examples)
 
     def __getitem__(self, item):
         if isinstance(item, slice):
-            return LazyAudio(self.examples[item])
+            return LazyAudio(self.examples[item], self.dtype)
         ex = dict(self.examples[item])
         min_num_samples = ex.get('end_orig', ex['end']) - ex['start']
         ex['audio_data'] = recursive_load_audio(
             ex['audio_path'], start=ex['start'], stop=ex['end'],
-            min_num_samples=min_num_samples)
+            min_num_samples=min_num_samples, dtype=self.dtype)
         return ex
 
     def __iter__(self):

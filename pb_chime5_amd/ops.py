@@ -340,7 +340,9 @@ class UtterancePipeline:
         slot = self._next
         self._next = (self._next + 1) % len(self.slots)
         ctx, p = self.slots[slot], self.params
-        obs = np.ascontiguousarray(obs, dtype=np.float64)
+        # int16 = PCM straight from the WAV files: converted on the device
+        pcm = np.asarray(obs).dtype == np.int16
+        obs = np.ascontiguousarray(obs, dtype=np.int16 if pcm else np.float64)
         act = np.ascontiguousarray((np.asarray(activity) != 0).astype(np.uint8))
         D, N = obs.shape
         K, N_act = act.shape
@@ -351,7 +353,8 @@ class UtterancePipeline:
         out_d = self._buffer(slot, 'out', 8 * max(n_out, 1))
         ctx.upload(obs_d, obs)
         ctx.upload(act_d, act)
-        ctx._check(ctx.lib.gss_enhance_observation(
+        entry = ctx.lib.gss_enhance_observation_pcm16 if pcm else ctx.lib.gss_enhance_observation
+        ctx._check(entry(
             ctx.handle, ctypes.byref(p), c_void_p(obs_d.ptr), D, N, c_void_p(act_d.ptr), K,
             N_act, int(target_index), int(start_context), int(end_context),
             c_void_p(out_d.ptr), None), 'gss_enhance_observation')

@@ -121,7 +121,7 @@ def test_enhance_example_fixture(gpu_ctx, golden, monkeypatch):
     arrays = sorted(ex['audio_path']['observation'])
     audio = {a: g[f'audio/{a}'] for a in arrays}
     monkeypatch.setattr(core, 'load_audio',
-                        lambda path, start=None, stop=None: audio[path][:, start:stop])
+                        lambda path, start=None, stop=None, dtype=None: audio[path][:, start:stop])
     total = audio['U01'].shape[1]
     store = {'S99': {}}
     for a in arrays:
@@ -499,3 +499,23 @@ def test_utterance_pipeline_is_bit_identical_to_one_at_a_time(gpu_ctx):
         assert sorted(got) == list(range(len(utts)))
         for i, w in enumerate(want):
             assert np.array_equal(got[i], w), (depth, i)
+
+
+def test_pcm16_input_is_bit_identical_to_float64(gpu_ctx):
+    """gss_enhance_observation_pcm16: int16 samples converted inside the STFT kernel
+    (x * 2^-15, what the reference's loader does on the host) -- same bits out."""
+    from pb_chime5_amd import ops, synthetic
+    u = synthetic.tiny(seed=9, num_channels=6, num_samples=20000, num_speakers=3)
+    pcm = np.clip(np.rint(u.obs / np.abs(u.obs).max() * 20000), -32768, 32767).astype(np.int16)
+    as_float = pcm.astype(np.float64) / 2 ** 15
+    cs = u.ex['start_orig']['original']
+    params = ops.make_params(wpe=True, wpe_taps=3, wpe_iterations=2, bss_iterations=4)
+    want = ops.enhance_observation(as_float, u.activity_array, u.target_index, cs, cs,
+                                   params=params, ctx=gpu_ctx)
+    pipe = ops.UtterancePipeline(params, depth=2, first_ctx=gpu_ctx)
+    pipe.enqueue('pcm', pcm, u.activity_array, u.target_index, cs, cs)
+    pipe.enqueue('f64', as_float, u.activity_array, u.target_index, cs, cs)
+    got = dict(pipe.pop() for _ in range(2))
+    pipe.close()
+    assert np.array_equal(got['f64'], want)
+    assert np.array_equal(got['pcm'], want)
