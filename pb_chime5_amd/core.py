@@ -263,6 +263,13 @@ class Enhancer:
         self._enhance_and_write(parallel.split_managed(it), audio_dir)
 
     def _write(self, ex, x_hat, audio_dir):
+        if not np.all(np.isfinite(x_hat)):
+            # Same outcome as the reference: e.g. an utterance so close to the end of the
+            # recording that the nominal end context (core.py:217-222 takes it from the
+            # example, not from the audio actually read) zeroes every frame of the target
+            # mask -> Phi_X = 0 -> 0 / 0 in the blind analytic normalisation.
+            import warnings
+            warnings.warn(f'{ex.get("example_id")}: the enhanced signal is not finite')
         dataset = mapping.session_to_dataset[ex['session_id']]
         if x_hat.ndim == 1:
             dump_audio(x_hat, Path(audio_dir) / f'{dataset}' / f'{ex["example_id"]}.wav')
