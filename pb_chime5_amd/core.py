@@ -260,7 +260,15 @@ class Enhancer:
             else:
                 raise ValueError(dataset_slice)
 
-        self._enhance_and_write(parallel.split_managed(it), audio_dir)
+        costs = None
+        if parallel.world_size() > 1:
+            # longest first, so that the last utterances handed out are short ones
+            def samples(tree):
+                if isinstance(tree, dict):
+                    return max((samples(v) for v in tree.values()), default=0)
+                return int(tree)
+            costs = [samples(ex['num_samples']) for ex in it]
+        self._enhance_and_write(parallel.split_managed(it, costs=costs), audio_dir)
 
     def _write(self, ex, x_hat, audio_dir):
         if not np.all(np.isfinite(x_hat)):
