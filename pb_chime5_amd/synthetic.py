@@ -154,7 +154,7 @@ def config5(seed=5, num_channels=12, seconds=120.0):
 
 
 def tiny(seed=0, num_channels=4, num_samples=12000, num_speakers=2,
-         context=2048):
+         context=2048, noise=1e-3):
     """Small case for smoke tests and CPU-sized parity checks."""
     n = num_samples
     rng = np.random.default_rng(seed + 31)
@@ -165,4 +165,4 @@ def tiny(seed=0, num_channels=4, num_samples=12000, num_speakers=2,
         intervals.append((a, a + length))
     return make_utterance(seed, num_channels, n, intervals, target=0,
                           start_context=context, end_context=context,
-                          rir_taps=512)
+                          rir_taps=512, noise=noise)

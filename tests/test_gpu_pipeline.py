@@ -458,6 +458,36 @@ def test_edge_single_class_and_two_channels(gpu_ctx):
     assert np.array_equal(np.isnan(got), np.isnan(want))
 
 
+@pytest.mark.parametrize('D,K', [(20, 4), (28, 3), (12, 6), (24, 2), (16, 3)])
+def test_other_channel_and_class_counts(gpu_ctx, D, K):
+    """Channel counts off the tuned paths: D = 20 / 28 / 16 take the LDS-form E-step and
+    other MFMA tile counts (wpe_apply with 1 or 2 channel tiles, 3 or 4 x 8 lanes in the
+    class update), D = 12 / 24 with K = 6 / 2 the register-form E-step at its limits."""
+    from pb_chime5_amd import synthetic
+    # enough frames per unknown (T = 254, taps * D <= 56) and sensor noise 30 dB below the
+    # speech (with 1 - 3 point sources on 12 - 28 microphones the spatial covariance is
+    # otherwise numerically singular) for a well-conditioned WPE
+    u = synthetic.tiny(seed=D + K, num_channels=D, num_samples=64000, num_speakers=K - 1,
+                       context=4096, noise=3e-2)
+    got, det, want, wdet = _run_both(u, wpe=True, wpe_taps=2, wpe_delay=2, wpe_iterations=2,
+                                     bss_iterations=6)
+    assert np.array_equal(det['acitivity_freq'], wdet['activity_freq'])
+    assert rel_err(det['Obs'], wdet['Obs']) < 1e-5
+    if det['ref_channel'] != wdet['ref_channel']:
+        # the argmax over channels of a cross-frequency SNR sum: accept another channel only
+        # if the oracle's own SNRs are tied there to rounding, or degenerate (see _stagewise)
+        cov_x, cov_n = wdet['cov_x'], wdet['cov_n']
+        phi = oracle.stable_solve(cov_n, cov_x)
+        mat = phi / np.maximum(np.trace(phi, axis1=-1, axis2=-2)[..., None, None].real, 1e-10)
+        num = np.einsum('FdR,FdD,FDR->R', mat.conj(), cov_x, mat).real
+        den = np.einsum('FdR,FdD,FDR->R', mat.conj(), cov_n, mat).real
+        snr = num / np.maximum(den, 1e-10)
+        assert snr.max() > 1e12 or snr[det['ref_channel']] >= snr.max() * (1 - 1e-6), snr
+        return
+    assert rel_err(np.abs(det['X_hat']), np.abs(wdet['X_hat'])) < TOL_STFT_MAG
+    assert rel_err(got, want) < TOL_STFT_MAG
+
+
 def test_unsupported_sizes_fail_loudly(gpu_ctx):
     from pb_chime5_amd import ops
     with pytest.raises(NotImplementedError):
