@@ -392,7 +392,23 @@ __global__ __launch_bounds__(64) void mvdr_ref_kernel(const cplx *__restrict__ s
     bool isnan_ = false;
     if (lane < D) {
         cplx num = c_make(0.0, 0.0), den = c_make(0.0, 0.0);
-        for (int f = 0; f < F; ++f) {
+        // fixed summation order (frequency ascending), loads issued 8 frequencies ahead
+        constexpr int UB = 8;
+        int f = 0;
+        for (; f + UB <= F; f += UB) {
+            cplx a[UB], b[UB];
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                a[j] = snr[((int64_t)(f + j) * D + lane) * 2];
+                b[j] = snr[((int64_t)(f + j) * D + lane) * 2 + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                num = c_add(num, a[j]);
+                den = c_add(den, b[j]);
+            }
+        }
+        for (; f < F; ++f) {
             num = c_add(num, snr[((int64_t)f * D + lane) * 2]);
             den = c_add(den, snr[((int64_t)f * D + lane) * 2 + 1]);
         }
