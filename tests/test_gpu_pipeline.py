@@ -549,3 +549,50 @@ def test_pcm16_input_is_bit_identical_to_float64(gpu_ctx):
     pipe.close()
     assert np.array_equal(got['f64'], want)
     assert np.array_equal(got['pcm'], want)
+
+
+def test_random_shapes_against_oracle(gpu_ctx):
+    """Seeded fuzz over channel / class / frame counts, context, WPE and EM settings, beamformer
+    and postfilter (scratch/fuzz.py is the exploratory version): every stage has partial-tile
+    and odd-size code paths that the BASELINE shapes never visit."""
+    from pb_chime5_amd import ops, synthetic
+    rng = np.random.default_rng(2024)
+    done = 0
+    for case in range(40):
+        D = int(rng.integers(2, 30)); K = int(rng.integers(3, 7))
+        N = int(rng.integers(9000, 36000)); ctx_s = int(rng.integers(0, 3000))
+        taps = int(rng.integers(1, 4)); delay = int(rng.integers(1, 4)); wit = int(rng.integers(1, 3))
+        bss = int(rng.integers(1, 5)); post = int(rng.integers(0, 3))
+        bf = ['mvdrSouden_ban', 'ch2', 'sum'][int(rng.integers(0, 3))]
+        if bf == 'ch2' and D < 3:
+            bf = 'sum'
+        pf = [None, 'mask_mul'][int(rng.integers(0, 2))]
+        wpe = bool(rng.integers(0, 4) > 0)
+        T = (N + 2 * 768 - 1024 + 255) // 256 + 1
+        if wpe and T < 3 * taps * D + 10:
+            continue                      # too few frames for a well-posed WPE
+        u = synthetic.tiny(seed=5000 + case, num_channels=D, num_samples=N, num_speakers=K - 1,
+                           context=ctx_s, noise=5e-2)
+        kw = dict(wpe=wpe, wpe_taps=taps, wpe_delay=delay, wpe_iterations=wit, bss_iterations=bss,
+                  bss_iterations_post=post, bf=bf, postfilter=pf)
+        got, det = ops.enhance_observation(u.obs, u.activity_array, u.target_index, ctx_s, ctx_s,
+                                           debug=True, ctx=gpu_ctx, **kw)
+        want, wdet = oracle.enhance_observation(u.obs, u.activity_array, u.target_index, u.ex,
+                                                return_details=True,
+                                                gss_fn=oracle.gss_block_batched, **kw)
+        tag = (case, D, K, N, kw)
+        assert got.shape == want.shape, tag
+        assert np.array_equal(det['acitivity_freq'], wdet['activity_freq'][:, :det['Obs'].shape[1]]), tag
+        assert rel_err(det['Obs'], wdet['Obs']) < 1e-6, tag
+        if bf == 'mvdrSouden_ban':
+            # bins with a nearly singular Phi_N are decided by rounding in the reference too
+            good = np.linalg.cond(wdet['cov_n']) < 1e8
+            assert good.mean() > 0.5, tag
+            if det['ref_channel'] == wdet['ref_channel']:
+                assert rel_err(np.abs(det['X_hat'][:, good]), np.abs(wdet['X_hat'][:, good])) \
+                    < TOL_STFT_MAG, tag
+        else:
+            assert rel_err(np.abs(det['X_hat']), np.abs(wdet['X_hat'])) < TOL_STFT_MAG, tag
+            assert rel_err(got, want) < TOL_STFT_MAG, tag
+        done += 1
+    assert done >= 15, done
