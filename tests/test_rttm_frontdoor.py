@@ -129,3 +129,71 @@ def test_enhance_session_end_to_end_vs_oracle(gpu_ctx, tmp_path):
     pcm = load_audio(wavs[1])
     ref = want * ((2 ** 15 - 1) / 2 ** 15 / np.max(np.abs(want)))
     assert np.max(np.abs(pcm - ref)) <= 1.01 / 2 ** 15
+
+
+# ---------------------------------------------------------------- reference fixture
+GOLDEN = __import__('pathlib').Path(__file__).parent / 'golden'
+
+
+def _reference_setup(tmp_path):
+    """The directory and RTTM that tests/golden/make_golden_rttm.py fed to the reference's
+    own rttm.py / core_chime6_rttm.py (the RTTM restricted to the session that has audio:
+    the reference builds examples for every session of the file)."""
+    root, rttm_file, audio = _make_chime6_dir(tmp_path)
+    rttm_file.write_text(''.join(l + '\n' for l in RTTM.splitlines() if ' S02' in l))
+    return root, rttm_file
+
+
+def _multiarray(tag):
+    return True if tag == 'True' else tag
+
+
+def test_examples_and_activity_match_reference(tmp_path):
+    """Example enumeration, ids, context, channel selection, audio cut to the shortest
+    file and the RTTM activity: bit exact against the reference's own code."""
+    from pb_chime5_amd.core_chime6_rttm import get_enhancer
+    from pb_chime5_amd.database.chime5 import rttm
+    fx = json.loads((GOLDEN / 'rttm_session.json').read_text())
+    root, rttm_file = _reference_setup(tmp_path)
+    assert rttm.RTTMDatabase.example_id('S02', '1', 100, 200) == fx['example_id']
+    for tag, case in fx['cases'].items():
+        enh = get_enhancer(database_rttm=str(rttm_file), activity_rttm=str(rttm_file),
+                           chime6_dir=str(root), multiarray=_multiarray(tag), **fx['enhancer'])
+        assert sorted(enh.db.dataset_names) == fx['dataset_names']
+        ds = enh.get_dataset('dev')
+        assert len(ds) == len(case['examples'])
+        for ex, want in zip(ds, case['examples']):
+            for key in ('example_id', 'start', 'end', 'num_samples', 'session_id', 'speaker_id',
+                        'dataset', 'start_orig', 'end_orig', 'num_samples_orig'):
+                assert ex[key] == want[key], (tag, key)
+            assert [p.split('/')[-1] for p in ex['audio_path']] == want['audio_files'], tag
+            assert list(ex['audio_data'].shape) == want['audio_shape'], tag
+        activity = enh.activity['S02']
+        assert list(activity.keys()) == list(case['activity'].keys())
+        for spk, want in case['activity'].items():
+            if want == 'ones':
+                assert activity[spk][5:50000].all()
+            else:
+                assert [list(map(int, iv)) for iv in activity[spk].normalized_intervals] == want
+
+
+@pytest.mark.gpu
+def test_enhance_example_matches_reference_fixture(gpu_ctx, tmp_path):
+    from pb_chime5_amd.core_chime6_rttm import get_enhancer
+    fx = json.loads((GOLDEN / 'rttm_session.json').read_text())
+    gold = np.load(GOLDEN / 'rttm_session.npz')
+    root, rttm_file = _reference_setup(tmp_path)
+    checked = 0
+    for tag in fx['cases']:
+        enh = get_enhancer(database_rttm=str(rttm_file), activity_rttm=str(rttm_file),
+                           chime6_dir=str(root), multiarray=_multiarray(tag), **fx['enhancer'])
+        ds = enh.get_dataset('dev')
+        for i in range(len(ds)):
+            key = f'{tag}/x_hat/{i}'
+            if key not in gold:
+                continue
+            got = enh.enhance_example(ds[i])
+            assert got.shape == gold[key].shape, key
+            assert rel_err(got, gold[key]) < 1e-4, key      # north-star tolerance
+            checked += 1
+    assert checked == 5
