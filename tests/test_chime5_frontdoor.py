@@ -314,3 +314,15 @@ def test_cli_run_test_run(corpus, tmp_path):
                         'reference_array=U02', '-F', str(tmp_path / 'store')])
     assert run_dir == tmp_path / 'store' / '1'
     assert len(list((run_dir / 'audio' / 'dev').glob('*.wav'))) == 2
+
+
+def test_session_tables_match_reference():
+    """mapping.py builds the CHiME-5 session tables from compact rules; the expected dicts
+    were dumped from the reference's pb_chime5/mapping.py:12-79 (tests/golden/mapping_tables.json)."""
+    from pb_chime5_amd import mapping
+    want = json.loads((GOLDEN / 'mapping_tables.json').read_text())
+    assert dict(mapping.session_to_speakers) == want['session_to_speakers']
+    assert dict(mapping.session_to_dataset) == want['session_to_dataset']
+    assert dict(mapping.session_to_arrays) == want['session_to_arrays']
+    with pytest.raises(KeyError):
+        mapping.session_to_dataset['S99']
