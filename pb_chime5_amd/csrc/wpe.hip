@@ -14,6 +14,7 @@
 // contraction of the hot path, done here with the f64 MFMA
 // (v_mfma_f64_16x16x4_f64) straight out of an LDS copy of the window.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "gss_internal.h"
@@ -54,13 +55,13 @@ struct CorrTile {
     int row_off, col_off, is_p, mask;   // mask: needed 16 x 16 sub-tiles, bit a * TS + b
 };
 
-// 1-D XCD-mapped grid over (tile groups, F); block: 256 = 4 waves, one
-// (16 TS) x (16 TS) tile each.  MASK (bit a * TS + b) says which 16 x 16 sub-tiles of
+// 1-D XCD-mapped grid over (tile groups, F); block: NW waves (4, or 2 when that packs the
+// chip better, see wpe_run), one (16 TS) x (16 TS) tile each.  MASK (bit a * TS + b) says which 16 x 16 sub-tiles of
 // the wave's tile are needed: diagonal tiles skip the sub-tile below the diagonal and
 // tiles on the edge of n (240 = 7.5 x 32) the half that lies outside, which removes
 // 15 % of the MFMAs at taps * D = 240.  The host sorts the tile list by mask so that the
 // four waves of a workgroup carry similar loads.
-template <int TS, bool M3, int MASK>
+template <int TS, bool M3, int MASK, int NW>
 __device__ __forceinline__ void corr_tile_body(
     const cplx *__restrict__ Yf, const double *__restrict__ wf, int64_t T, int D, int n, int c,
     int frames_lds, cplx *S, double *wS, const CorrTile tl, bool active, int f,
@@ -95,7 +96,8 @@ __device__ __forceinline__ void corr_tile_body(
     // MFMAs of chunk i are issued and written to LDS after them, so the global-load
     // latency hides under the matrix work (elements beyond CORR_STG * 256 -- only for
     // very wide windows -- are staged synchronously).
-    constexpr int CORR_STG = 8;
+    constexpr int NT = 64 * NW;              // threads of the workgroup
+    constexpr int CORR_STG = 2048 / NT;
     const int total = frames_lds * D;
     cplx stg[CORR_STG];
     double stg_w = 0.0;
@@ -103,7 +105,7 @@ __device__ __forceinline__ void corr_tile_body(
         const int64_t fr0 = t0 - c;
 #pragma unroll
         for (int s = 0; s < CORR_STG; ++s) {
-            const int idx = threadIdx.x + 256 * s;
+            const int idx = threadIdx.x + NT * s;
             const int64_t fr = fr0 + idx / D;
             stg[s] = c_make(0.0, 0.0);
             if (idx < total && fr >= 0 && fr < T) stg[s] = Yf[fr0 * D + idx];
@@ -113,12 +115,12 @@ __device__ __forceinline__ void corr_tile_body(
     auto stage_store = [&](int64_t t0) {
 #pragma unroll
         for (int s = 0; s < CORR_STG; ++s) {
-            const int idx = threadIdx.x + 256 * s;
+            const int idx = threadIdx.x + NT * s;
             if (idx < total) S[idx] = stg[s];
         }
         if (threadIdx.x < CORR_KT) wS[threadIdx.x] = stg_w;
         const int64_t fr0 = t0 - c;
-        for (int idx = threadIdx.x + 256 * CORR_STG; idx < total; idx += blockDim.x) {
+        for (int idx = threadIdx.x + NT * CORR_STG; idx < total; idx += blockDim.x) {
             const int64_t fr = fr0 + idx / D;
             S[idx] = (fr >= 0 && fr < T) ? Yf[fr0 * D + idx] : c_make(0.0, 0.0);
         }
@@ -227,8 +229,8 @@ __device__ __forceinline__ void corr_tile_body(
             }
 }
 
-template <int TS, bool M3>
-__global__ __launch_bounds__(256) void wpe_corr_kernel(
+template <int TS, bool M3, int NW>
+__global__ __launch_bounds__(64 * NW) void wpe_corr_kernel(
     const cplx *__restrict__ Y, const double *__restrict__ w, int F, int64_t T, int D, int n,
     int c, int padf, const CorrTile *__restrict__ tiles, int ntiles, cplx *__restrict__ R,
     cplx *__restrict__ P) {
@@ -238,9 +240,9 @@ __global__ __launch_bounds__(256) void wpe_corr_kernel(
     double *wS = reinterpret_cast<double *>(S + frames_lds * D);   // CORR_KT
 
     int f, grp;
-    if (!xcd_group_map((ntiles + 3) / 4, F, f, grp)) return;
+    if (!xcd_group_map((ntiles + NW - 1) / NW, F, f, grp)) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile_id = grp * 4 + wave;
+    const int tile_id = grp * NW + wave;
     const bool active = tile_id < ntiles;
     const CorrTile tl = tiles[active ? tile_id : 0];
     const cplx *Yf = Y + (int64_t)f * T * D;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void wpe_corr_kernel(
     constexpr int FULL = (1 << (TS * TS)) - 1;
     const int mask = __builtin_amdgcn_readfirstlane(active ? tl.mask : 1);
 #define CORR_CASE(M) \
-    case M: corr_tile_body<TS, M3, M>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P); break
+    case M: corr_tile_body<TS, M3, M, NW>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P); break
     if (TS == 2) {
         switch (mask) {
             CORR_CASE(1);
@@ -256,10 +258,10 @@ __global__ __launch_bounds__(256) void wpe_corr_kernel(
             CORR_CASE(5);
             CORR_CASE(11);
             default:
-                corr_tile_body<TS, M3, FULL>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P);
+                corr_tile_body<TS, M3, FULL, NW>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P);
         }
     } else {
-        corr_tile_body<TS, M3, FULL>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P);
+        corr_tile_body<TS, M3, FULL, NW>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P);
     }
 #undef CORR_CASE
 }
@@ -889,7 +891,23 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     // 3 real MFMAs per complex product (t1 = ar br, t2 = ai bi, t3 = (ar + ai)(br - bi));
     // GSS_CORR_4M=1 selects the 4-product form
     const bool corr_3m = getenv("GSS_CORR_4M") == nullptr;
-    auto corr_fn = corr_3m ? wpe_corr_kernel<corr_ts, true> : wpe_corr_kernel<corr_ts, false>;
+    // Waves per workgroup.  A workgroup lives for the whole frame loop, so the launch runs in
+    // ceil(workgroups / resident slots) rounds: with F = 513 = 2 * 256 + 1 frequencies the
+    // 4-wave form can leave a last round almost empty (D = 12, taps 10: 2052 workgroups on
+    // 1024 slots = 3 rounds for 2.004 rounds of work).  Two waves per workgroup stage the
+    // window twice as often per tile but pack 8 workgroups per CU.
+    const size_t corr_lds_probe = sizeof(cplx) * (size_t)(CORR_KT + c + corr_padf(D, 16 * corr_ts)) * D +
+                                  sizeof(double) * CORR_KT;
+    auto round_eff = [&](int nw) {
+        const double wgs = (double)((ntiles + nw - 1) / nw) * F;
+        const int by_regs = 16 / nw, by_lds = (int)(160 * 1024 / corr_lds_probe);
+        const double rounds = wgs / (256.0 * std::max(1, std::min(by_regs, by_lds)));
+        return rounds / std::ceil(rounds);
+    };
+    int corr_nw = round_eff(2) > round_eff(4) + 0.15 ? 2 : 4;
+    if (const char *e = getenv("GSS_CORR_NW")) corr_nw = atoi(e) == 2 ? 2 : 4;
+    auto corr_fn = corr_nw == 2 ? (corr_3m ? wpe_corr_kernel<corr_ts, true, 2> : wpe_corr_kernel<corr_ts, false, 2>)
+                                : (corr_3m ? wpe_corr_kernel<corr_ts, true, 4> : wpe_corr_kernel<corr_ts, false, 4>);
     const size_t corr_lds = sizeof(cplx) * (size_t)(CORR_KT + c + padf) * D + sizeof(double) * CORR_KT;
     const size_t panel_lds = sizeof(cplx) * CH_NB * UD_LD + sizeof(double) * CH_NB;
     static_assert(BS_LD <= UD_LD, "S must fit in Ud");
@@ -916,7 +934,8 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         }
         {
             GSS_PROF(ctx, "wpe_corr");
-            hipLaunchKernelGGL(corr_fn, dim3(xcd_grid((ntiles + 3) / 4, F)), dim3(256), corr_lds,
+            hipLaunchKernelGGL(corr_fn, dim3(xcd_grid((ntiles + corr_nw - 1) / corr_nw, F)),
+                               dim3(64 * corr_nw), corr_lds,
                                ctx->stream, Y, w, F, T, D, n, c, padf, tiles_dev, ntiles, R, P);
             GSS_LAUNCH_CHECK(ctx, "wpe_corr_kernel");
         }
