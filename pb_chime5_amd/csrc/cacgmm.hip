@@ -18,6 +18,7 @@
 //    B_k,de = sum_t w_kt P_de(t)
 // where Mq holds B_k^-1 with the off-diagonals doubled.  That is 4 real FMAs per
 // (entry, class, frame) instead of 12 for the dense form.
+#include <cmath>
 #include <cstdlib>
 
 #include "gss_internal.h"
@@ -261,12 +262,15 @@ __global__ __launch_bounds__(256) void em_estep_reg_kernel(EmArgs a, const cplx 
                                                            const cplx *__restrict__ Yn) {
     constexpr int NE = D * (D + 1) / 2;
     const int64_t T = a.T;
-    const int ntile = (int)((T + 255) / 256);
+    // waves are independent (no LDS, no barrier): the workgroup size only decides how the
+    // launch packs into rounds of resident workgroups (see estep_waves_per_block)
+    const int wpb = blockDim.x >> 6;
+    const int ntile = (int)((T + 64 * wpb - 1) / (64 * wpb));
     int f, tile;
     if (!xcd_group_map(ntile, a.F, f, tile)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t t = (int64_t)tile * 256 + wave * 64 + lane;
+    const int64_t t = ((int64_t)tile * wpb + wave) * 64 + lane;
     const bool valid = t < T;
     const int64_t tc = valid ? t : T - 1;
     const cplx *Mf = Mq + (int64_t)f * NE * K;
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(256) void em_estep_reg_kernel(EmArgs a, const cplx 
         } else {
             if (valid) a.W[((int64_t)f * K + k) * T + t] = gam / fmax(q[k], 10.0 * GSS_TINY);
             const double tot = wave_sum(valid ? gam : 0.0);
-            if (lane == 0) a.Sg[(((int64_t)f * ntile + tile) * 4 + wave) * K + k] = tot;
+            if (lane == 0) a.Sg[(((int64_t)f * ntile + tile) * wpb + wave) * K + k] = tot;
         }
     }
 }
@@ -796,10 +800,26 @@ int launch_estep(gss_ctx *ctx, int mode, const EmArgs &a, const cplx *Mq, int F)
     return GSS_OK;
 }
 
+// Waves per workgroup of the register-form E-step: 1 or 4, whichever fills the rounds of
+// resident workgroups better (16 waves per CU at ~118 VGPRs).  At T = 941, F = 513: 4 waves
+// give 2052 workgroups on 1024 slots -- 2.004 rounds, i.e. a third round for 4 workgroups;
+// single waves give 7695 on 4096 = 1.88 rounds.
+int estep_waves_per_block(int F, int64_t T) {
+    auto eff = [&](int wpb) {
+        const double wgs = (double)((T + 64 * wpb - 1) / (64 * wpb)) * F;
+        const double rounds = wgs / (256.0 * (16 / wpb));
+        return rounds / std::ceil(rounds);
+    };
+    static const int forced = getenv("GSS_ESTEP_WPB") ? atoi(getenv("GSS_ESTEP_WPB")) : 0;
+    if (forced == 1 || forced == 4) return forced;
+    return eff(1) > eff(4) ? 1 : 4;
+}
+
 template <int K, int D>
 int launch_estep_reg(gss_ctx *ctx, int mode, const EmArgs &a, const cplx *Mq, const cplx *Yn,
                      int F) {
-    const dim3 grid(xcd_grid((int)((a.T + 255) / 256), F)), block(256);
+    const int wpb = estep_waves_per_block(F, a.T);
+    const dim3 grid(xcd_grid((int)((a.T + 64 * wpb - 1) / (64 * wpb)), F)), block(64 * wpb);
     if (mode == MODE_EM) {
         GSS_PROF(ctx, "em_estep");
         hipLaunchKernelGGL((em_estep_reg_kernel<K, D, MODE_EM>), grid, block, 0, ctx->stream, a,
@@ -895,7 +915,7 @@ size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K) {
     b += align_up(sizeof(double) * (size_t)F * nch * K);         // Sg
     b += align_up(sizeof(int) * (size_t)F * K);                  // need_eigh
     b += align_up(sizeof(cplx) * (size_t)F * D * T);             // Yn (register-form E-step)
-    b += align_up(sizeof(double) * (size_t)F * 4 * ((T + 255) / 256) * K);
+    b += align_up(sizeof(double) * (size_t)F * ((T + 63) / 64 + 4) * K);
     return b + 4096;
 }
 
@@ -925,7 +945,8 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     // register-form E-step: normalised observation in (F, D, T) layout, its own
     // (finer) partial sums of gamma
     const bool reg = estep_reg_supported(D, K) && getenv("GSS_ESTEP_LDS") == nullptr;
-    const int reg_nch = 4 * (int)((T + 255) / 256);
+    const int reg_wpb = estep_waves_per_block(F, T);
+    const int reg_nch = reg_wpb * (int)((T + 64 * reg_wpb - 1) / (64 * reg_wpb));
     cplx *Yn = nullptr;
     double *Sg_lds = a.Sg, *Sg_reg = nullptr;
     const int nch_lds = a.nch;
