@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void em_estep_reg_kernel(EmArgs a, const cplx 
 // CACGMM M-step (unit-normalised y, K class weights) and by the PSD matrices of the
 // beamformer (raw y, target / distortion masks).
 struct WcovLds {
-    int Dp, nblk, nfg;
+    int Dp, nblk, nfg, red_groups;   // red_groups: frame groups reduced per round
     size_t ys, wk, scratch, blk, total;
 };
 
@@ -364,8 +364,15 @@ __host__ __device__ inline WcovLds wcov_lds_layout(int D, int KW) {
     L.nfg = nfg;
     size_t off = 0;
     const size_t ys_bytes = sizeof(cplx) * (size_t)L.Dp * EM_TS;
-    const size_t red_bytes = sizeof(cplx) * (size_t)L.nblk * 4 * KW;
-    L.ys = off;                                   // the final reduction reuses the tile
+    // the final reduction over the frame groups reuses the tile; with few channels there
+    // are up to 64 groups, which go through LDS many at a time (up to 32 KB)
+    const size_t group_bytes = sizeof(cplx) * (size_t)L.nblk * 4 * KW;
+    int rg = (int)((32 * 1024) / group_bytes);
+    if (rg > nfg - 1) rg = nfg - 1;
+    if (rg < 1) rg = 1;
+    L.red_groups = rg;
+    const size_t red_bytes = group_bytes * rg;
+    L.ys = off;
     off += ys_bytes > red_bytes ? ys_bytes : red_bytes;
     L.wk = off;      off += sizeof(double) * KW * EM_TILE;
     L.scratch = off; off += sizeof(double) * 4 * EM_TILE;
@@ -456,23 +463,29 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
             }
         }
     }
-    // reduce the frame groups (group fg > 0 -> LDS -> group 0), then store
+    // reduce the frame groups (groups fg > 0 -> LDS -> group 0, red_groups per round, always
+    // added in ascending group order), then store
     cplx *red = reinterpret_cast<cplx *>(smem + L.ys);
-    for (int r = 1; r < L.nfg; ++r) {
+    const int gstride = L.nblk * 4 * KW;
+    for (int r0 = 1; r0 < L.nfg; r0 += L.red_groups) {
         __syncthreads();
-        if (m_active && fg == r) {
+        if (m_active && fg >= r0 && fg < r0 + L.red_groups) {
+            cplx *dst = red + (size_t)(fg - r0) * gstride;
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int k = 0; k < KW; ++k) red[(mb * 4 + s) * KW + k] = acc[s][k];
+                for (int k = 0; k < KW; ++k) dst[(mb * 4 + s) * KW + k] = acc[s][k];
         }
         __syncthreads();
         if (fg == 0) {
+            for (int r = r0; r < r0 + L.red_groups && r < L.nfg; ++r) {
+                const cplx *src = red + (size_t)(r - r0) * gstride;
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int k = 0; k < KW; ++k)
-                    acc[s][k] = c_add(acc[s][k], red[(mb * 4 + s) * KW + k]);
+                    for (int k = 0; k < KW; ++k)
+                        acc[s][k] = c_add(acc[s][k], src[(mb * 4 + s) * KW + k]);
+            }
         }
     }
     if (fg == 0) {
