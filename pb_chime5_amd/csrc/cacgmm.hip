@@ -381,7 +381,7 @@ __host__ __device__ inline WcovLds wcov_lds_layout(int D, int KW) {
     return L;
 }
 
-template <int KW, bool NORMALISE, bool SRC_FDT>
+template <int KW, bool NORMALISE, bool SRC_FDT, bool PREFETCH = false>
 __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
                                                    const double *__restrict__ W, int F,
                                                    int64_t T, int D, int NE, int nch,
@@ -424,21 +424,57 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
 #pragma unroll
         for (int k = 0; k < KW; ++k) acc[s][k] = c_make(0.0, 0.0);
 
+    // PREFETCH (few channels, where a workgroup has next to no arithmetic per tile and would
+    // sit at the barriers waiting for its loads): the NEXT tile is fetched into registers
+    // before the accumulation over the current one and written to LDS after it.
+    constexpr int WPRE = (KW * EM_TILE + 255) / 256;
+    cplx ypre[8];
+    double wpre[WPRE];
+    auto prefetch = [&](int64_t t0) {
+        const cplx *src = Y + (int64_t)f * D * T;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = g + 4 * j;
+            ypre[j] = (d < D && t0 + tl < c1) ? src[(int64_t)d * T + t0 + tl] : c_make(0.0, 0.0);
+        }
+#pragma unroll
+        for (int j = 0; j < WPRE; ++j) {
+            const int idx = tid + 256 * j;
+            const int k = idx / EM_TILE, jj = idx - k * EM_TILE;
+            wpre[j] = (idx < KW * EM_TILE && t0 + jj < c1) ? Wf[(int64_t)k * T + t0 + jj] : 0.0;
+        }
+    };
+    if (SRC_FDT && PREFETCH) prefetch(c0);
     for (int64_t t0 = c0; t0 < c1; t0 += EM_TILE) {
         __syncthreads();
-        if (SRC_FDT) {
-            // Y is already the (F, D, T) unit-normalised copy: rows are contiguous
-            const cplx *src = Y + (int64_t)f * D * T;
-            for (int d = g; d < D; d += 4)
-                ys[d * EM_TS + tl] = t0 + tl < c1 ? src[(int64_t)d * T + t0 + tl] : c_make(0.0, 0.0);
+        if (SRC_FDT && PREFETCH) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = g + 4 * j;
+                if (d < D) ys[d * EM_TS + tl] = ypre[j];
+            }
+#pragma unroll
+            for (int j = 0; j < WPRE; ++j) {
+                const int idx = tid + 256 * j;
+                if (idx < KW * EM_TILE) wk[idx] = wpre[j];
+            }
+            __syncthreads();
+            if (t0 + EM_TILE < c1) prefetch(t0 + EM_TILE);
         } else {
-            load_tile<NORMALISE>(Yf, D, t0, c1, tl, g, ys, scratch);
+            if (SRC_FDT) {
+                // Y is already the (F, D, T) unit-normalised copy: rows are contiguous
+                const cplx *src = Y + (int64_t)f * D * T;
+                for (int d = g; d < D; d += 4)
+                    ys[d * EM_TS + tl] = t0 + tl < c1 ? src[(int64_t)d * T + t0 + tl] : c_make(0.0, 0.0);
+            } else {
+                load_tile<NORMALISE>(Yf, D, t0, c1, tl, g, ys, scratch);
+            }
+            for (int idx = tid; idx < KW * EM_TILE; idx += blockDim.x) {
+                const int k = idx / EM_TILE, j = idx - k * EM_TILE;
+                wk[idx] = t0 + j < c1 ? Wf[(int64_t)k * T + t0 + j] : 0.0;
+            }
+            __syncthreads();
         }
-        for (int idx = tid; idx < KW * EM_TILE; idx += blockDim.x) {
-            const int k = idx / EM_TILE, j = idx - k * EM_TILE;
-            wk[idx] = t0 + j < c1 ? Wf[(int64_t)k * T + t0 + j] : 0.0;
-        }
-        __syncthreads();
         if (m_active) {
             const int nfr = (int)min((int64_t)EM_TILE, c1 - t0);
             const int bi = blk[2 * mb], bj = blk[2 * mb + 1];
@@ -867,9 +903,18 @@ int launch_mstep(gss_ctx *ctx, const EmArgs &a, const cplx *Yn, int F) {
     const size_t lds = wcov_lds_layout(a.D, K).total;
     GSS_PROF(ctx, "em_mstep");
     if (Yn) {
-        GSS_TRY(raise_lds_limit(ctx, wcov_kernel<K, false, true>, lds));
-        hipLaunchKernelGGL((wcov_kernel<K, false, true>), dim3(xcd_grid(a.nch, F)), dim3(256), lds,
-                           ctx->stream, Yn, a.W, F, a.T, a.D, a.NE, a.nch, a.chunk_frames, a.Bp);
+        static const int pf_max_d = getenv("GSS_MSTEP_PREFETCH_D") ? atoi(getenv("GSS_MSTEP_PREFETCH_D")) : 20;
+        if (a.D <= pf_max_d) {
+            GSS_TRY(raise_lds_limit(ctx, wcov_kernel<K, false, true, true>, lds));
+            hipLaunchKernelGGL((wcov_kernel<K, false, true, true>), dim3(xcd_grid(a.nch, F)),
+                               dim3(256), lds, ctx->stream, Yn, a.W, F, a.T, a.D, a.NE, a.nch,
+                               a.chunk_frames, a.Bp);
+        } else {
+            GSS_TRY(raise_lds_limit(ctx, wcov_kernel<K, false, true>, lds));
+            hipLaunchKernelGGL((wcov_kernel<K, false, true>), dim3(xcd_grid(a.nch, F)), dim3(256),
+                               lds, ctx->stream, Yn, a.W, F, a.T, a.D, a.NE, a.nch, a.chunk_frames,
+                               a.Bp);
+        }
         GSS_LAUNCH_CHECK(ctx, "wcov_kernel");
         return GSS_OK;
     }
@@ -963,7 +1008,8 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     cplx *Yn = nullptr;
     double *Sg_lds = a.Sg, *Sg_reg = nullptr;
     const int nch_lds = a.nch;
-    if (reg) {
+    {
+        // the unit-normalised (F, D, T) copy also feeds the M-step of every channel count
         Yn = arena_alloc_t<cplx>(ctx, (size_t)F * D * T);
         Sg_reg = arena_alloc_t<double>(ctx, (size_t)F * reg_nch * K);
         GSS_REQUIRE(ctx, Yn && Sg_reg, GSS_ERR_NOMEM, "cacgmm workspace");
