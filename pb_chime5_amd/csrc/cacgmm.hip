@@ -234,9 +234,9 @@ __global__ __launch_bounds__(256) void em_estep_kernel(EmArgs a, const cplx *__r
 }
 
 // ------------------------------------------------------------------ E-step, register form
-// For the channel counts that matter (D = 24: 6 arrays x 4, D = 12: outer mics of 6
-// arrays) the E-step runs without LDS and without any barrier: the unit-normalised
-// observation is kept once per utterance in (F, D, T) layout (em_prepare), a lane owns
+// For the channel counts of the corpus (all / outer / reference-array microphones of its
+// 5 and 6 array sessions: D = 24, 20, 12, 10, 4) the E-step runs without LDS and without
+// any barrier: the unit-normalised observation is kept once per utterance in (F, D, T) layout (em_prepare), a lane owns
 // one frame, pulls its D channel values with coalesced loads into registers, walks the
 // packed upper triangle fully unrolled with the model row in SGPRs (scalar loads), and
 // finishes the softmax in registers.  Lanes never exchange data.
@@ -534,6 +534,82 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
                 const int e = tri_index(d1, d2, D);
 #pragma unroll
                 for (int k = 0; k < KW; ++k) pp[k * NE + e] = acc[s][k];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ M-step, register form
+// One reference array (D = 4): the packed triangle of all K classes fits the registers of
+// one lane (4 real diagonals + 6 complex off-diagonals = 16 doubles per class), so a lane
+// owns frames, a wave owns a chunk, and nothing goes through LDS: coalesced loads from the
+// (F, D, T) copy and the (F, K, T) weights, the next frame requested before the current
+// one is accumulated, one cross-lane sum per entry at the end.  The tiled kernel above
+// would spend its time at the barriers of 64-frame tiles that carry 3 blocks of work.
+template <int K, int D>
+__global__ __launch_bounds__(64) void mstep_reg_kernel(const cplx *__restrict__ Yn,
+                                                       const double *__restrict__ W, int F,
+                                                       int64_t T, int nch, int chunk_frames,
+                                                       cplx *__restrict__ part) {
+    constexpr int NE = D * (D + 1) / 2;
+    int f, chunk;
+    if (!xcd_group_map(nch, F, f, chunk)) return;
+    const int lane = threadIdx.x;
+    const int64_t c0 = (int64_t)chunk * chunk_frames;
+    const int64_t c1 = c0 + chunk_frames < T ? c0 + chunk_frames : T;
+    const cplx *yf = Yn + (int64_t)f * D * T;
+    const double *wf = W + (int64_t)f * K * T;
+
+    double are[K][NE], aim[K][NE];          // aim of the diagonal entries stays unused
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) are[k][e] = aim[k][e] = 0.0;
+
+    cplx y[D], yn[D];
+    double w[K], wn[K];
+    auto fetch = [&](int64_t t, cplx (&yy)[D], double (&ww)[K]) {
+        const bool ok = t < c1;
+        const int64_t tc = ok ? t : c1 - 1;
+#pragma unroll
+        for (int d = 0; d < D; ++d) yy[d] = yf[(int64_t)d * T + tc];
+#pragma unroll
+        for (int k = 0; k < K; ++k) ww[k] = ok ? wf[(int64_t)k * T + tc] : 0.0;
+    };
+    fetch(c0 + lane, yn, wn);
+    for (int64_t tb = c0; tb < c1; tb += 64) {                      // wave uniform
+#pragma unroll
+        for (int d = 0; d < D; ++d) y[d] = yn[d];
+#pragma unroll
+        for (int k = 0; k < K; ++k) w[k] = wn[k];
+        if (tb + 64 < c1) fetch(tb + 64 + lane, yn, wn);
+        int e = 0;
+#pragma unroll
+        for (int d1 = 0; d1 < D; ++d1) {
+#pragma unroll
+            for (int d2 = d1; d2 < D; ++d2, ++e) {
+                const double pr = y[d1].x * y[d2].x + y[d1].y * y[d2].y;
+#pragma unroll
+                for (int k = 0; k < K; ++k) are[k][e] = fma(w[k], pr, are[k][e]);
+                if (d2 != d1) {
+                    const double pim = y[d1].y * y[d2].x - y[d1].x * y[d2].y;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) aim[k][e] = fma(w[k], pim, aim[k][e]);
+                }
+            }
+        }
+    }
+    cplx *pp = part + ((int64_t)f * nch + chunk) * K * NE;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        int e = 0;
+#pragma unroll
+        for (int d1 = 0; d1 < D; ++d1) {
+#pragma unroll
+            for (int d2 = d1; d2 < D; ++d2, ++e) {
+                const double re = wave_sum(are[k][e]);
+                const double im = d2 != d1 ? wave_sum(aim[k][e]) : 0.0;
+                if (lane == 0) pp[k * NE + e] = c_make(re, im);
             }
         }
     }
@@ -883,7 +959,11 @@ int launch_estep_reg(gss_ctx *ctx, int mode, const EmArgs &a, const cplx *Mq, co
 }
 
 // Channel / class counts with a register-form E-step.
-bool estep_reg_supported(int D, int K) { return (D == 24 || D == 12) && K >= 2 && K <= 6; }
+// D = 4 x arrays (all microphones), 2 x arrays (outer microphones) or 4 (reference array)
+// for the 5 and 6 array sessions of the corpus.
+bool estep_reg_supported(int D, int K) {
+    return (D == 24 || D == 20 || D == 12 || D == 10 || D == 4) && K >= 2 && K <= 6;
+}
 
 template <int D>
 int launch_estep_reg_k(gss_ctx *ctx, int K, int mode, const EmArgs &a, const cplx *Mq,
@@ -902,6 +982,13 @@ template <int K>
 int launch_mstep(gss_ctx *ctx, const EmArgs &a, const cplx *Yn, int F) {
     const size_t lds = wcov_lds_layout(a.D, K).total;
     GSS_PROF(ctx, "em_mstep");
+    if (Yn && a.D == 4 && K >= 2 && K <= 6 && getenv("GSS_MSTEP_TILED") == nullptr) {
+        hipLaunchKernelGGL((mstep_reg_kernel<(K >= 2 && K <= 6 ? K : 2), 4>),
+                           dim3(xcd_grid(a.nch, F)), dim3(64), 0, ctx->stream, Yn, a.W, F, a.T,
+                           a.nch, a.chunk_frames, a.Bp);
+        GSS_LAUNCH_CHECK(ctx, "mstep_reg_kernel");
+        return GSS_OK;
+    }
     if (Yn) {
         static const int pf_max_d = getenv("GSS_MSTEP_PREFETCH_D") ? atoi(getenv("GSS_MSTEP_PREFETCH_D")) : 20;
         if (a.D <= pf_max_d) {
@@ -1023,8 +1110,13 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     auto estep = [&](int mode) -> int {
         if (reg && mode != MODE_FIRST) {
             a.Sg = Sg_reg;
-            if (D == 24) return launch_estep_reg_k<24>(ctx, K, mode, a, Mq, Yn, F);
-            return launch_estep_reg_k<12>(ctx, K, mode, a, Mq, Yn, F);
+            switch (D) {
+                case 24: return launch_estep_reg_k<24>(ctx, K, mode, a, Mq, Yn, F);
+                case 20: return launch_estep_reg_k<20>(ctx, K, mode, a, Mq, Yn, F);
+                case 12: return launch_estep_reg_k<12>(ctx, K, mode, a, Mq, Yn, F);
+                case 10: return launch_estep_reg_k<10>(ctx, K, mode, a, Mq, Yn, F);
+                default: return launch_estep_reg_k<4>(ctx, K, mode, a, Mq, Yn, F);
+            }
         }
         a.Sg = Sg_lds;
         return launch_estep_k(ctx, K, mode, a, Mq, F);
