@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void wpe_power_kernel(const cplx *__restrict__
 
 // ------------------------------------------------------------------ correlation (MFMA)
 constexpr int CORR_KT = 64;   // frames staged per chunk
+constexpr int CORR_FINE_MAX_SUBTILES = 48;   // up to here (D <= 12 at 10 taps): one wave per 16 x 16 sub-tile
 
 struct CorrTile {
     int row_off, col_off, is_p, mask;   // mask: needed 16 x 16 sub-tiles, bit a * TS + b
@@ -97,7 +98,7 @@ __device__ __forceinline__ void corr_tile_body(
     // latency hides under the matrix work (elements beyond CORR_STG * 256 -- only for
     // very wide windows -- are staged synchronously).
     constexpr int NT = 64 * NW;              // threads of the workgroup
-    constexpr int CORR_STG = 2048 / NT;
+    constexpr int CORR_STG = NW == 1 ? 8 : (TS == 1 ? 1024 : 2048) / NT;
     const int total = frames_lds * D;
     cplx stg[CORR_STG];
     double stg_w = 0.0;
@@ -145,6 +146,10 @@ __device__ __forceinline__ void corr_tile_body(
                 b_cur[m] = base[tl.col_off + 16 * m];
             }
         }
+        // (one-sub-tile waves are not unrolled all the way: hoisting 16 k-steps of operand
+        // loads costs the registers that let a fourth and fifth wave share the SIMD)
+        constexpr int KU = TS == 1 ? 4 : 16;
+#pragma unroll KU
         for (int ks = 0; ks < ksteps; ++ks) {
             if (ks + 1 < ksteps) {
                 const int kf = 4 * (ks + 1) + lk;
@@ -845,7 +850,16 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
 
     // tile lists: correlation tiles, then one trailing-update list per block column
     std::vector<CorrTile> tiles;
-    constexpr int corr_ts = 2;       // 32 x 32 wave tiles (48 x 48 measured slower)
+    // 32 x 32 wave tiles (48 x 48 measured slower).  With few channels (one array: taps * D
+    // = 40 is 3 sub-tiles of 16 wide, 9 needed in all) the 32 x 32 list is a handful of
+    // unequal tiles per frequency and the launch is bound by its heaviest waves, so there
+    // every needed 16 x 16 sub-tile becomes a wave of its own: equal loads, more waves,
+    // fewer registers each.  Measured (T = 2169, ms per launch, 32 x 32 -> 16 x 16):
+    // D = 4: 0.53 -> 0.33, D = 10: 1.33 -> 1.12, D = 12: 1.50 -> 1.36, D = 20: 3.40 -> 3.92,
+    // D = 24: 4.16 -> 5.11.
+    const int sub16 = (n + 15) / 16;
+    int corr_ts = sub16 * (sub16 + 1) / 2 + sub16 * ((D + 15) / 16) <= CORR_FINE_MAX_SUBTILES ? 1 : 2;
+    if (const char *e = getenv("GSS_CORR_TS")) corr_ts = atoi(e) == 1 ? 1 : 2;
     const int ntiles = corr_tiles(n, D, c, 16 * corr_ts, tiles);
     // trailing-update tiles: 16 x 16, every tile that reaches the upper triangle (larger
     // register tiles -- 2 x 2, 2 x 3, 3 x 3 MFMA tiles per wave -- measured slower: the
@@ -904,10 +918,18 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         const double rounds = wgs / (256.0 * std::max(1, std::min(by_regs, by_lds)));
         return rounds / std::ceil(rounds);
     };
-    int corr_nw = round_eff(2) > round_eff(4) + 0.15 ? 2 : 4;
-    if (const char *e = getenv("GSS_CORR_NW")) corr_nw = atoi(e) == 2 ? 2 : 4;
-    auto corr_fn = corr_nw == 2 ? (corr_3m ? wpe_corr_kernel<corr_ts, true, 2> : wpe_corr_kernel<corr_ts, false, 2>)
-                                : (corr_3m ? wpe_corr_kernel<corr_ts, true, 4> : wpe_corr_kernel<corr_ts, false, 4>);
+    int corr_nw = corr_ts == 2 && round_eff(2) > round_eff(4) + 0.15 ? 2 : 4;
+    if (const char *e = getenv("GSS_CORR_NW")) corr_nw = atoi(e) == 2 ? 2 : atoi(e) == 1 && corr_ts == 1 ? 1 : 4;
+    // one array: the window is a few KB, every wave stages its own and the hardware
+    // balances single waves (no idle wave in a workgroup, no barrier partner to wait for)
+    if (corr_ts == 1 && (size_t)(CORR_KT + c + padf) * D <= 512 && !getenv("GSS_CORR_NW")) corr_nw = 1;
+    auto corr_fn = corr_ts == 1 && corr_nw == 1
+        ? (corr_3m ? wpe_corr_kernel<1, true, 1> : wpe_corr_kernel<1, false, 1>)
+        : corr_ts == 1
+        ? (corr_nw == 2 ? (corr_3m ? wpe_corr_kernel<1, true, 2> : wpe_corr_kernel<1, false, 2>)
+                        : (corr_3m ? wpe_corr_kernel<1, true, 4> : wpe_corr_kernel<1, false, 4>))
+        : (corr_nw == 2 ? (corr_3m ? wpe_corr_kernel<2, true, 2> : wpe_corr_kernel<2, false, 2>)
+                        : (corr_3m ? wpe_corr_kernel<2, true, 4> : wpe_corr_kernel<2, false, 4>));
     const size_t corr_lds = sizeof(cplx) * (size_t)(CORR_KT + c + padf) * D + sizeof(double) * CORR_KT;
     const size_t panel_lds = sizeof(cplx) * CH_NB * UD_LD + sizeof(double) * CH_NB;
     static_assert(BS_LD <= UD_LD, "S must fit in Ud");
