@@ -664,12 +664,14 @@ __global__ __launch_bounds__(256) void chol_backsolve_kernel(const cplx *__restr
 // slots.  NB (channel tiles) is a template parameter: a run-time tile count inside the
 // k loop makes the compiler shuttle the accumulators between VGPRs and AGPRs around
 // every MFMA and wait for each result.
-template <int TA, int NB>
-__global__ __launch_bounds__(256) void wpe_apply_kernel(const cplx *__restrict__ Y,
+// M3: three real MFMAs per complex product as in the correlation (t1 = sum ur gr,
+// t2 = sum ui gi, t3 = sum (ur + ui)(gr - gi); re = t1 + t2, im = t3 - t1 + t2).
+template <int TA, int NB, bool M3, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void wpe_apply_kernel(const cplx *__restrict__ Y,
                                                         const cplx *__restrict__ G, int F,
                                                         int64_t T, int D, int n, int c,
                                                         cplx *__restrict__ X) {
-    constexpr int WAVE_FRAMES = 16 * TA, WG_FRAMES = 4 * WAVE_FRAMES;
+    constexpr int WAVE_FRAMES = 16 * TA, WG_FRAMES = NWV * WAVE_FRAMES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx *S = reinterpret_cast<cplx *>(smem);   // (WG_FRAMES + c + 2) * DP
     const int DP = D | 1;
@@ -680,53 +682,58 @@ __global__ __launch_bounds__(256) void wpe_apply_kernel(const cplx *__restrict__
     const cplx *Gf = G + (int64_t)f * n * D;
     const int frames_lds = WG_FRAMES + c + 2;
     const int64_t fr0 = t0 - c;
-    for (int idx = threadIdx.x; idx < frames_lds * D; idx += blockDim.x) {
-        const int fl = idx / D, d = idx - fl * D;
-        const int64_t fr = fr0 + fl;
-        cplx v = c_make(0.0, 0.0);
-        if (fr >= 0 && fr < T) v = Yf[fr0 * D + idx];
-        S[fl * DP + d] = v;
+    // window -> LDS, 8 loads in flight per thread (one load per trip is a chain of
+    // dependent round trips as long as the whole k loop)
+    constexpr int PRE = 8, NT = 64 * NWV;
+    const int total = frames_lds * D;
+    for (int base = 0; base < total; base += NT * PRE) {
+        cplx v[PRE];
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) {
+            const int idx = base + (int)threadIdx.x + NT * j;
+            const int64_t fr = fr0 + idx / D;
+            v[j] = c_make(0.0, 0.0);
+            if (idx < total && fr >= 0 && fr < T) v[j] = Yf[fr0 * D + idx];
+        }
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) {
+            const int idx = base + (int)threadIdx.x + NT * j;
+            const int fl = idx / D, d = idx - fl * D;
+            if (idx < total) S[fl * DP + d] = v[j];
+        }
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
     const int wf0 = wave * WAVE_FRAMES;          // first frame of this wave, tile relative
-    v4d acc_re[TA][NB], acc_im[TA][NB];
+    v4d acc_re[TA][NB], acc_im[TA][NB], acc_t2[M3 ? TA : 1][M3 ? NB : 1];
 #pragma unroll
     for (int a = 0; a < TA; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             acc_re[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
             acc_im[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+            if (M3) acc_t2[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
         }
-    // loads are unconditional (clamped address, zero selected afterwards) and the k loop
-    // has no branch: with control flow inside it the compiler keeps the accumulators in
-    // VGPRs and copies them to AGPRs and back around every group of MFMAs
-    auto load_b = [&](int ks, cplx (&g)[NB]) {
-        const int r = 4 * ks + lk;
-        const int rc = min(r, n - 1);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int d = 16 * b + li;
-            const cplx v = Gf[(int64_t)rc * D + min(d, D - 1)];
-            const bool ok = r < n && d < D;
-            g[b] = c_make(ok ? v.x : 0.0, ok ? v.y : 0.0);
-        }
-    };
+    // Two k-steps per trip with ping-pong operand registers: G rows (global, L2 resident)
+    // and window fragments (LDS) of k-step ks + 1 are requested before the MFMAs of ks are
+    // issued and first touched a k-step later, so neither latency sits between two groups
+    // of MFMAs.  Loads are unconditional (clamped addresses); rows r >= n are cancelled by
+    // zeroing the window operand, channel slots d >= D are computed and never stored.  The
+    // k loop has no branch: with control flow inside it the compiler keeps the accumulators
+    // in VGPRs and copies them to AGPRs and back around every group of MFMAs.
     const int ksteps = (n + 3) / 4;
-    cplx g_cur[NB], g_nxt[NB];
-    load_b(0, g_cur);
+    const int lds_last = frames_lds * DP - 1;
+    auto load_g = [&](int ks, cplx (&g)[NB]) {
+        const int rc = min(4 * ks + lk, n - 1);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) g[b] = Gf[(int64_t)rc * D + min(16 * b + li, D - 1)];
+    };
     // r = 4 ks + lk = rq D + rm, advanced without dividing
     int rq = lk / D, rm = lk - rq * D;
-    for (int ks = 0; ks < ksteps; ++ks) {
-        load_b(min(ks + 1, ksteps - 1), g_nxt);
-        double ur[TA], ui[TA], gr[NB], gi[NB], ngi[NB];
+    auto load_u = [&](cplx (&u)[TA]) {
 #pragma unroll
-        for (int a = 0; a < TA; ++a) {
-            const cplx u = S[(wf0 + 16 * a + li + rq) * DP + rm];
-            ur[a] = u.x;
-            ui[a] = u.y;
-        }
+        for (int a = 0; a < TA; ++a) u[a] = S[min((wf0 + 16 * a + li + rq) * DP + rm, lds_last)];
         rm += 4;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {   // D >= 1: at most 4 wraps, branch free
@@ -734,29 +741,69 @@ __global__ __launch_bounds__(256) void wpe_apply_kernel(const cplx *__restrict__
             rm -= wrap ? D : 0;
             rq += wrap ? 1 : 0;
         }
+    };
+    auto step = [&](int ks, const cplx (&g)[NB], const cplx (&u)[TA]) {
+        const bool ok = 4 * ks + lk < n;
+        double ur[TA], ui[TA], gr[NB], gi[NB];
+#pragma unroll
+        for (int a = 0; a < TA; ++a) {
+            ur[a] = ok ? u[a].x : 0.0;
+            ui[a] = ok ? u[a].y : 0.0;
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            gr[b] = g_cur[b].x;
-            gi[b] = g_cur[b].y;
-            ngi[b] = -g_cur[b].y;
+            gr[b] = g[b].x;
+            gi[b] = g[b].y;
         }
         // u * conj(g)
+        if (M3) {
+            // acc_re = t1, acc_t2 = t2, acc_im = t3
+            double us[TA], gd[NB];
 #pragma unroll
-        for (int a = 0; a < TA; ++a)
+            for (int a = 0; a < TA; ++a) us[a] = ur[a] + ui[a];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[a], gr[b], acc_re[a][b], 0, 0, 0);
-                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui[a], gr[b], acc_im[a][b], 0, 0, 0);
-            }
+            for (int b = 0; b < NB; ++b) gd[b] = gr[b] - gi[b];
 #pragma unroll
-        for (int a = 0; a < TA; ++a)
+            for (int a = 0; a < TA; ++a)
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui[a], gi[b], acc_re[a][b], 0, 0, 0);
-                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[a], ngi[b], acc_im[a][b], 0, 0, 0);
-            }
+                for (int b = 0; b < NB; ++b) {
+                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[a], gr[b], acc_re[a][b], 0, 0, 0);
+                    acc_t2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui[a], gi[b], acc_t2[a][b], 0, 0, 0);
+                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(us[a], gd[b], acc_im[a][b], 0, 0, 0);
+                }
+        } else {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) g_cur[b] = g_nxt[b];
+            for (int a = 0; a < TA; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[a], gr[b], acc_re[a][b], 0, 0, 0);
+                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui[a], gr[b], acc_im[a][b], 0, 0, 0);
+                }
+#pragma unroll
+            for (int a = 0; a < TA; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui[a], gi[b], acc_re[a][b], 0, 0, 0);
+                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[a], -gi[b], acc_im[a][b], 0, 0, 0);
+                }
+        }
+    };
+    cplx g0[NB], g1[NB], u0[TA], u1[TA];
+    load_g(0, g0);
+    load_u(u0);
+    for (int ks = 0; ks < ksteps; ks += 2) {
+        // (scheduling barriers: left alone, the compiler gathers both loads at the top of
+        // the trip and waits for them before the first MFMA)
+        load_g(ks + 1, g1);
+        load_u(u1);
+        __builtin_amdgcn_sched_barrier(0);
+        step(ks, g0, u0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_g(ks + 2, g0);
+        load_u(u0);
+        __builtin_amdgcn_sched_barrier(0);
+        step(ks + 1, g1, u1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     // C/D fragment: col = li (channel), row = lk + 4 * reg (frame)
 #pragma unroll
@@ -770,8 +817,10 @@ __global__ __launch_bounds__(256) void wpe_apply_kernel(const cplx *__restrict__
                 const int64_t t = t0 + fl;
                 if (d < D && t < T) {
                     const cplx y = S[(fl + c) * DP + d];
-                    X[((int64_t)f * T + t) * D + d] =
-                        c_make(y.x - acc_re[a][b][reg], y.y - acc_im[a][b][reg]);
+                    const double pre = M3 ? acc_re[a][b][reg] + acc_t2[a][b][reg] : acc_re[a][b][reg];
+                    const double pim = M3 ? (acc_im[a][b][reg] - acc_re[a][b][reg]) + acc_t2[a][b][reg]
+                                          : acc_im[a][b][reg];
+                    X[((int64_t)f * T + t) * D + d] = c_make(y.x - pre, y.y - pim);
                 }
             }
 }
@@ -933,8 +982,18 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     const size_t corr_lds = sizeof(cplx) * (size_t)(CORR_KT + c + padf) * D + sizeof(double) * CORR_KT;
     const size_t panel_lds = sizeof(cplx) * CH_NB * UD_LD + sizeof(double) * CH_NB;
     static_assert(BS_LD <= UD_LD, "S must fit in Ud");
-    constexpr int apply_ta = 2, apply_frames = 64 * apply_ta;
-    auto apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1> : wpe_apply_kernel<apply_ta, 2>;
+    constexpr int apply_ta = 2;
+    const bool apply_3m = getenv("GSS_APPLY_4M") == nullptr;
+    int apply_nwv = getenv("GSS_APPLY_NWV") ? atoi(getenv("GSS_APPLY_NWV")) : 4;
+    if (apply_nwv != 2 && apply_nwv != 3) apply_nwv = 4;
+    if (!apply_3m) apply_nwv = 4;
+    const int apply_frames = 16 * apply_ta * apply_nwv;
+    auto apply_fn = D <= 16 ? (apply_3m ? wpe_apply_kernel<apply_ta, 1, true> : wpe_apply_kernel<apply_ta, 1, false>)
+                            : (apply_3m ? wpe_apply_kernel<apply_ta, 2, true> : wpe_apply_kernel<apply_ta, 2, false>);
+    if (apply_3m && apply_nwv == 2)
+        apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, true, 2> : wpe_apply_kernel<apply_ta, 2, true, 2>;
+    if (apply_3m && apply_nwv == 3)
+        apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, true, 3> : wpe_apply_kernel<apply_ta, 2, true, 3>;
     const size_t apply_lds = sizeof(cplx) * (size_t)(apply_frames + c + 2) * (D | 1);
     GSS_REQUIRE(ctx, corr_lds <= 160 * 1024 && apply_lds <= 160 * 1024, GSS_ERR_UNSUPPORTED,
                 "wpe: taps=%d D=%d needs more LDS than a CU has", taps, D);
@@ -999,7 +1058,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
             GSS_PROF(ctx, "wpe_apply");
             hipLaunchKernelGGL(apply_fn,
                                dim3(xcd_grid((int)((T + apply_frames - 1) / apply_frames), F)),
-                               dim3(256), apply_lds, ctx->stream, Y, P, F, T, D, n, c, X);
+                               dim3(64 * apply_nwv), apply_lds, ctx->stream, Y, P, F, T, D, n, c, X);
             GSS_LAUNCH_CHECK(ctx, "wpe_apply_kernel");
         }
     }
