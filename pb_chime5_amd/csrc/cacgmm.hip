@@ -626,6 +626,15 @@ __device__ __forceinline__ void tri_unpack(int e, int D, int &d1, int &d2) {
     d2 = d1 + rem;
 }
 
+// sum over the E-step's partial sums of gamma_k: one load per lane and a fixed reduction
+// tree (a serial loop is a chain of dependent L2 round trips, one per partial sum).
+__device__ inline double sum_gamma(const double *__restrict__ Sg, int sg_nch, int K, int k, int f,
+                                   int lane) {
+    double s = 0.0;
+    for (int c = lane; c < sg_nch; c += 64) s += Sg[((int64_t)f * sg_nch + c) * K + k];
+    return wave_sum(s);
+}
+
 // B_k = D * (sum over chunks of the partial sums) / max(sum gamma, tiny): every lane
 // reduces its packed entries e = lane, lane + 64, ... into `vals` (at most
 // COV_SLOTS = ceil(528 / 64) of them).  All chunk loads of an entry are issued before
@@ -643,15 +652,14 @@ __device__ inline double reduce_covariance(const cplx *__restrict__ Bp, int nch,
         cplx v = c_make(0.0, 0.0);
         if (e < NE) {
             const cplx *src = Bp + ((int64_t)f * nch * K + k) * NE + e;
-            int c = 0;
-            for (; c + 8 <= nch; c += 8) {
+            for (int c = 0; c < nch; c += 8) {
                 cplx t[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) t[j] = src[(int64_t)(c + j) * K * NE];
+                for (int j = 0; j < 8; ++j)
+                    t[j] = c + j < nch ? src[(int64_t)(c + j) * K * NE] : c_make(0.0, 0.0);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v = c_add(v, t[j]);
             }
-            for (; c < nch; ++c) v = c_add(v, src[(int64_t)c * K * NE]);
             v.x = ((double)D * v.x) / den;
             v.y = ((double)D * v.y) / den;
         }
@@ -840,8 +848,7 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
     cplx *A = reinterpret_cast<cplx *>(smem);                  // D * (8 NR + 1) + D doubles
     const int k = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
 
-    double sg = 0.0;
-    for (int c = 0; c < sg_nch; ++c) sg += Sg[((int64_t)f * sg_nch + c) * K + k];
+    const double sg = sum_gamma(Sg, sg_nch, K, k, f, lane);
     const double den = fmax(sg, GSS_TINY);
     if (lane == 0) pi[f * K + k] = sg / (double)T;
 
@@ -866,8 +873,7 @@ __global__ __launch_bounds__(64) void em_eigh_kernel(const cplx *__restrict__ Bp
     if (!need_eigh[f * K + k]) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NE = tri_count(D);
-    double sg = 0.0;
-    for (int c = 0; c < sg_nch; ++c) sg += Sg[((int64_t)f * sg_nch + c) * K + k];
+    const double sg = sum_gamma(Sg, sg_nch, K, k, f, lane);
     const double den = fmax(sg, GSS_TINY);
     cplx vals[COV_SLOTS];
     reduce_covariance(Bp, nch, D, K, k, f, den, vals, lane);

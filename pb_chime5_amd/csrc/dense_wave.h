@@ -70,69 +70,68 @@ __device__ inline void invert_lower_wave(cplx *A, int n, int ld, int lane) {
 // U[j][k] / dinv[j] for k > j, W[j][k] / dinv[j] for k < j, the pivot a_jj at k = j --
 // and dinv[j] = 1 / U[j][j] (0 where the pivot was not positive and finite); callers
 // scale when they consume.  Returns false (uniformly) if any pivot failed.
+// The steps are grouped by the block row jb = j / G they fall into (an unrolled loop), so
+// that "row / column block before, in, or after the pivot's block" is known at compile
+// time: row blocks above the pivot's are finished (no work), W entries take no column
+// beyond it, and only the pivot's own blocks need per-lane selects.
 template <int G, int NR, bool ONE_WAVE = false>
 __device__ __forceinline__ bool chol_inverse_sweep(cplx (&reg)[NR][NR], int n, cplx *M, int ld,
                                           double *dinv, int tx, int ty) {
     bool ok = true;
-    for (int j = 0; j < n; ++j) {
-        // row j = block row j / G of the owners (ty == j % G); select it without
-        // indexing the register array dynamically
-        cplx pub[NR];
 #pragma unroll
-        for (int b = 0; b < NR; ++b) pub[b] = reg[0][b];
+    for (int jb = 0; jb < NR; ++jb) {
+        for (int jj = 0; jj < G; ++jj) {
+            const int j = G * jb + jj;
+            if (j >= n) break;                      // uniform
+            // the owners of row j (ty == jj, register row jb) publish it
+            if (ty == jj) {
 #pragma unroll
-        for (int a = 1; a < NR; ++a)
-            if (j >= G * a) {
-#pragma unroll
-                for (int b = 0; b < NR; ++b) pub[b] = reg[a][b];
+                for (int b = 0; b < NR; ++b) M[j * ld + tx + G * b] = reg[jb][b];
             }
-        if (ty == j % G) {
+            if (ONE_WAVE) wave_sync();
+            else __syncthreads();
+            // all LDS reads of the step are issued together, unconditionally
+            const double ajj = M[j * ld + j].x;
+            cplx ru[NR], rv[NR];
 #pragma unroll
-            for (int b = 0; b < NR; ++b) M[j * ld + tx + G * b] = pub[b];
-        }
-        if (ONE_WAVE) wave_sync();
-        else __syncthreads();
-        // all LDS reads of the step are issued together, unconditionally
-        const double ajj = M[j * ld + j].x;
-        cplx ru[NR], rv[NR];
+            for (int a = jb; a < NR; ++a) ru[a] = M[j * ld + ty + G * a];
 #pragma unroll
-        for (int a = 0; a < NR; ++a) ru[a] = M[j * ld + ty + G * a];
-#pragma unroll
-        for (int b = 0; b < NR; ++b) rv[b] = M[j * ld + tx + G * b];
-        double di = 0.0;
-        if (ajj > 0.0 && isfinite(ajj)) di = rsqrt(ajj);
-        else ok = false;
-        if (tx == 0 && ty == 0) dinv[j] = di;
-        cplx u[NR], v[NR];
-#pragma unroll
-        for (int a = 0; a < NR; ++a) {
+            for (int b = 0; b < NR; ++b) rv[b] = M[j * ld + tx + G * b];
+            double di = 0.0;
+            if (ajj > 0.0 && isfinite(ajj)) di = rsqrt(ajj);
+            else ok = false;
+            if (tx == 0 && ty == 0) dinv[j] = di;
             // conj(U[j][i]) for the rows below the pivot, 0 elsewhere
-            const double s = ty + G * a > j ? di : 0.0;
-            u[a] = c_make(ru[a].x * s, -ru[a].y * s);
-        }
+            cplx u[NR];
 #pragma unroll
-        for (int b = 0; b < NR; ++b) {
-            // k > j: U[j][k];  k < j: W[j][k];  k == j: W[j][j] = 1 / U[j][j]
-            v[b] = tx + G * b == j ? c_make(di, 0.0) : c_scale(rv[b], di);
-        }
-        // entry (a, b) is an upper (U) entry when b > a, a W entry when b < a, and on
-        // a == b it depends on the thread; W entries only take columns k <= j
-        cplx vw[NR], vd[NR];
-#pragma unroll
-        for (int b = 0; b < NR; ++b) {
-            vw[b] = tx + G * b <= j ? v[b] : c_make(0.0, 0.0);
-            vd[b] = tx >= ty ? v[b] : vw[b];
-        }
-#pragma unroll
-        for (int a = 0; a < NR; ++a)
-#pragma unroll
-            for (int b = 0; b < NR; ++b) {
-                const cplx vv = b > a ? v[b] : (b < a ? vw[b] : vd[b]);
-                reg[a][b].x = fma(-u[a].x, vv.x, reg[a][b].x);
-                reg[a][b].x = fma(u[a].y, vv.y, reg[a][b].x);
-                reg[a][b].y = fma(-u[a].x, vv.y, reg[a][b].y);
-                reg[a][b].y = fma(-u[a].y, vv.x, reg[a][b].y);
+            for (int a = jb; a < NR; ++a) {
+                const double s = a > jb ? di : (ty > jj ? di : 0.0);
+                u[a] = c_make(ru[a].x * s, -ru[a].y * s);
             }
+            // k > j: U[j][k];  k < j: W[j][k];  k == j: W[j][j] = 1 / U[j][j]
+            cplx v[NR];
+#pragma unroll
+            for (int b = 0; b < NR; ++b) v[b] = c_scale(rv[b], di);
+            if (tx == jj) v[jb] = c_make(di, 0.0);
+            // W entries only take columns k <= j
+            const cplx vw_jb = tx <= jj ? v[jb] : c_make(0.0, 0.0);
+#pragma unroll
+            for (int a = jb; a < NR; ++a)
+#pragma unroll
+                for (int b = 0; b < NR; ++b) {
+                    // entry (a, b): upper (U) when b > a, W when b < a, per thread on a == b
+                    if (b < a && b > jb) continue;
+                    cplx vv;
+                    if (b > a) vv = v[b];
+                    else if (b < a) vv = b < jb ? v[b] : vw_jb;
+                    else if (b == jb) vv = tx >= ty ? v[b] : vw_jb;
+                    else vv = tx >= ty ? v[b] : c_make(0.0, 0.0);      // b > jb
+                    reg[a][b].x = fma(-u[a].x, vv.x, reg[a][b].x);
+                    reg[a][b].x = fma(u[a].y, vv.y, reg[a][b].x);
+                    reg[a][b].y = fma(-u[a].x, vv.y, reg[a][b].y);
+                    reg[a][b].y = fma(-u[a].y, vv.x, reg[a][b].y);
+                }
+        }
     }
     if (ONE_WAVE) wave_sync();
     else __syncthreads();
