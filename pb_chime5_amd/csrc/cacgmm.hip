@@ -616,14 +616,17 @@ __global__ __launch_bounds__(64) void mstep_reg_kernel(const cplx *__restrict__ 
 }
 
 // ------------------------------------------------------------------ model update
+// Packed upper triangle, row major: row d1 starts at s(d1) = d1 (2 D - d1 + 1) / 2.  Closed
+// form (float square root, corrected by at most one either way; checked exhaustively for
+// D <= 64) -- a search loop costs up to D trips and the class update unpacks 20 entries.
 __device__ __forceinline__ void tri_unpack(int e, int D, int &d1, int &d2) {
-    d1 = 0;
-    int rem = e;
-    while (rem >= D - d1) {
-        rem -= D - d1;
-        ++d1;
-    }
-    d2 = d1 + rem;
+    const float b = 2.0f * (float)D + 1.0f;
+    int r = (int)((b - sqrtf(b * b - 8.0f * (float)e)) * 0.5f);
+    r = max(0, min(r, D - 1));
+    if (r * (2 * D - r + 1) / 2 > e) --r;
+    else if ((r + 1) * (2 * D - r) / 2 <= e) ++r;
+    d1 = r;
+    d2 = r + e - r * (2 * D - r + 1) / 2;
 }
 
 // sum over the E-step's partial sums of gamma_k: one load per lane and a fixed reduction
@@ -755,20 +758,21 @@ __device__ __forceinline__ bool class_update_chol(const cplx (&vals)[COV_SLOTS],
     double ldv = 0.0;   // ln det B = 2 sum ln U_ii
     for (int i = lane; i < D; i += 64) ldv -= 2.0 * log(dinv[i]);
     ldv = wave_sum(ldv);
-    // W = U^-H: scale the unscaled rows of the sweep (strictly lower part), set the diagonal
-    for (int idx = lane; idx < D * D; idx += 64) {
-        const int i = idx / D, kk = idx - i * D;
-        if (kk < i) A[i * ld + kk] = c_scale(A[i * ld + kk], dinv[i]);
-        else if (kk == i) A[i * ld + i] = c_make(dinv[i], 0.0);
-    }
-    wave_sync();
-    // B^-1 = W^H W :  (d1,d2) = sum_{j >= d2} conj(W[j][d1]) W[j][d2]
+    // W = U^-H from the unscaled rows of the sweep: W[j][k] = A[j][k] dinv[j] (k < j),
+    // W[j][j] = dinv[j].  B^-1 = W^H W :  (d1,d2) = sum_{j >= d2} conj(W[j][d1]) W[j][d2]
+    //   = dinv[d2]^2 (d1 == d2 ? 1 : conj(A[d2][d1]))
+    //     + sum_{j > d2} dinv[j]^2 conj(A[j][d1]) A[j][d2]
     double ni2 = 0.0;
     for (int e = lane; e < NE; e += 64) {
         int d1, d2;
         tri_unpack(e, D, d1, d2);
-        cplx v = c_make(0.0, 0.0);
-        for (int j = d2; j < D; ++j) c_cfma(v, A[j * ld + d1], A[j * ld + d2]);
+        const double s2 = dinv[d2] * dinv[d2];
+        cplx v = d1 == d2 ? c_make(s2, 0.0) : c_scale(c_conj(A[d2 * ld + d1]), s2);
+        for (int j = d2 + 1; j < D; ++j) {
+            const double sj = dinv[j] * dinv[j];
+            const cplx p = c_scale(A[j * ld + d1], sj);
+            c_cfma(v, p, A[j * ld + d2]);
+        }
         if (d1 == d2) {
             v.y = 0.0;
             ni2 += v.x * v.x;
