@@ -279,8 +279,8 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_kernel(
 //   chol_diag    grid (F), one wave:   factor the 48 x 48 diagonal block in LDS and
 //                                      invert it: W = U_JJ^-H (lower triangular) is
 //                                      kept in the unused strictly-lower triangle
-//   chol_trsm    grid (chunks, F):     row panel  U_J = W A_J  (and Z_J = W P_J)
-//   chol_update  grid (tiles, F):      trailing update C -= U_J^H U_J with the f64
+//   chol_trsm    XCD grid (chunks x F): row panel  U_J = W A_J  (and Z_J = W P_J)
+//   chol_update  XCD grid (tiles x F): trailing update C -= U_J^H U_J with the f64
 //                                      MFMA, one 48 x 48 tile per wave, accumulators
 //                                      loaded from / stored to global memory in
 //                                      fragment layout, operands double-buffered
@@ -388,16 +388,19 @@ __device__ inline void chol_panel_tile(cplx *A, cplx *Z, int n, int D, int j0, i
 // grid (ceil(tiles / 4), F), block 256: every workgroup stages the factored diagonal
 // block of its frequency in LDS, then each wave takes one column tile.
 __global__ __launch_bounds__(256) void chol_trsm_kernel(cplx *__restrict__ R,
-                                                        cplx *__restrict__ P, int n, int D,
-                                                        int j0) {
+                                                        cplx *__restrict__ P, int F, int n,
+                                                        int D, int j0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx *Ud = reinterpret_cast<cplx *>(smem);                       // CH_NB * UD_LD
     double *dinv = reinterpret_cast<double *>(Ud + CH_NB * UD_LD);   // CH_NB
-    const int f = blockIdx.y, tid = threadIdx.x;
-    cplx *A = R + (int64_t)f * n * n;
-    cplx *Z = P + (int64_t)f * n * D;
+    const int tid = threadIdx.x;
     const int nb = min(CH_NB, n - j0);
     const int ntrail = n - j0 - nb;
+    const int npanel = (ntrail + 15) / 16 + (D + 15) / 16;
+    int f, grp;       // the workgroups of one frequency share one XCD (one L2)
+    if (!xcd_group_map((npanel + 3) / 4, F, f, grp)) return;
+    cplx *A = R + (int64_t)f * n * n;
+    cplx *Z = P + (int64_t)f * n * D;
     for (int idx = tid; idx < CH_NB * CH_NB; idx += blockDim.x) {
         const int i = idx / CH_NB, k = idx - i * CH_NB;
         cplx v = c_make(0.0, 0.0);
@@ -406,8 +409,8 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(cplx *__restrict__ R,
         if (k == i) dinv[i] = v.x > 0.0 ? 1.0 / v.x : 0.0;
     }
     __syncthreads();
-    const int ct = blockIdx.x * 4 + (tid >> 6);
-    if (ct < (ntrail + 15) / 16 + (D + 15) / 16) chol_panel_tile(A, Z, n, D, j0, nb, ct, Ud, dinv, tid & 63);
+    const int ct = grp * 4 + (tid >> 6);
+    if (ct < npanel) chol_panel_tile(A, Z, n, D, j0, nb, ct, Ud, dinv, tid & 63);
 }
 
 struct UpdTile {
@@ -515,16 +518,19 @@ __device__ inline void chol_update_tile(cplx *A, cplx *Z, int n, int D, int j0, 
             }
 }
 
-// grid (tile groups, F), block 256 = 4 waves, one tile each.
+// XCD-mapped 1-D grid over (tile groups, F), block 256 = 4 waves, one tile each.
 template <int TM, int TN, bool PREFETCH>
 __global__ __launch_bounds__(256) void chol_update_kernel(cplx *__restrict__ R,
-                                                          cplx *__restrict__ P, int n, int D,
-                                                          int j0, int nb,
+                                                          cplx *__restrict__ P, int F, int n,
+                                                          int D, int j0, int nb,
                                                           const UpdTile *__restrict__ tiles,
                                                           int ntiles) {
-    const int f = blockIdx.y;
+    // 1-D XCD-mapped grid: the tiles of one frequency run on one XCD, so its panel is
+    // fetched into one L2 instead of all eight
+    int f, grp;
+    if (!xcd_group_map((ntiles + 3) / 4, F, f, grp)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile_id = blockIdx.x * 4 + wave;
+    const int tile_id = grp * 4 + wave;
     if (tile_id >= ntiles) return;
     chol_update_tile<TM, TN, PREFETCH>(R + (int64_t)f * n * n, P + (int64_t)f * n * D, n, D, j0,
                                        nb, tiles[tile_id], lane);
@@ -1033,17 +1039,17 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                 {
                     GSS_PROF(ctx, "wpe_chol_trsm");
                     const int npanel = (n - j0 - nb + 15) / 16 + (D + 15) / 16;
-                    hipLaunchKernelGGL(chol_trsm_kernel, dim3((npanel + 3) / 4, F), dim3(256),
-                                       panel_lds, ctx->stream, R, P, n, D, j0);
+                    hipLaunchKernelGGL(chol_trsm_kernel, dim3(xcd_grid((npanel + 3) / 4, F)),
+                                       dim3(256), panel_lds, ctx->stream, R, P, F, n, D, j0);
                     GSS_LAUNCH_CHECK(ctx, "chol_trsm_kernel");
                 }
                 const int nupd = upd_count[J];
                 if (nupd > 0) {
                     GSS_PROF(ctx, "wpe_chol_update");
-                    const dim3 g((nupd + 3) / 4, F), b(256);
+                    const dim3 g(xcd_grid((nupd + 3) / 4, F)), b(256);
                     const UpdTile *tl = upd_dev + upd_start[J];
                     hipLaunchKernelGGL((chol_update_kernel<1, 1, true>), g, b, 0, ctx->stream, R, P,
-                                       n, D, j0, nb, tl, nupd);
+                                       F, n, D, j0, nb, tl, nupd);
                     GSS_LAUNCH_CHECK(ctx, "chol_update_kernel");
                 }
             }
