@@ -1,7 +1,7 @@
 """Per-kernel profile of one bench configuration: python scratch/kprof.py [n_top]"""
 import json, subprocess, sys
 out = subprocess.run([sys.executable, 'bench.py', '--steps', '6', '--warmup', '2', '--no-cpu-baseline',
-                      '--no-overlap-info'], capture_output=True, text=True)
+                      ], capture_output=True, text=True)
 line = out.stdout.strip().splitlines()[-1]
 d = json.loads(line)
 print('value', round(d['value'], 1), 'ms/step', round(d['ms_per_step'], 3))
