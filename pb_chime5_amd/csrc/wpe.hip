@@ -576,25 +576,33 @@ __device__ inline void chol_backsolve_body(const cplx *A, cplx *Z, int n, int D,
                         g[b] = (kv && col < D) ? Z[(int64_t)kk * D + col] : c_make(0.0, 0.0);
                     }
                 };
-                cplx u_cur, g_cur[2], u_nxt, g_nxt[2];
-                if (ksteps > 0) load_ops(0, u_cur, g_cur);
-                for (int ks = 0; ks < ksteps; ++ks) {
-                    if (ks + 1 < ksteps) load_ops(ks + 1, u_nxt, g_nxt);
-                    // acc -= u * g
-                    const double nur = -u_cur.x, nui = -u_cur.y, ui = u_cur.y;
+                // One workgroup per frequency and 1.5 waves per SIMD: nothing hides the operand
+                // latency but the wave itself, so the operands run PD k-steps ahead in a ring
+                // (static slots: the k loop advances PD steps per trip; steps past the end load
+                // zeros and add nothing).
+                constexpr int PD = 6;
+                cplx u_r[PD], g_r[PD][2];
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        acc_re[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nur, g_cur[b].x, acc_re[b], 0, 0, 0);
-                        acc_im[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nur, g_cur[b].y, acc_im[b], 0, 0, 0);
-                    }
+                for (int p = 0; p < PD; ++p) load_ops(p, u_r[p], g_r[p]);
+                for (int ks0 = 0; ks0 < ksteps; ks0 += PD) {
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        acc_re[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui, g_cur[b].y, acc_re[b], 0, 0, 0);
-                        acc_im[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nui, g_cur[b].x, acc_im[b], 0, 0, 0);
+                    for (int p = 0; p < PD; ++p) {
+                        // acc -= u * g
+                        const double nur = -u_r[p].x, nui = -u_r[p].y, ui = u_r[p].y;
+                        const double g0r = g_r[p][0].x, g0i = g_r[p][0].y;
+                        const double g1r = g_r[p][1].x, g1i = g_r[p][1].y;
+                        load_ops(ks0 + p + PD, u_r[p], g_r[p]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc_re[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(nur, g0r, acc_re[0], 0, 0, 0);
+                        acc_im[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(nur, g0i, acc_im[0], 0, 0, 0);
+                        acc_re[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(nur, g1r, acc_re[1], 0, 0, 0);
+                        acc_im[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(nur, g1i, acc_im[1], 0, 0, 0);
+                        acc_re[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui, g0i, acc_re[0], 0, 0, 0);
+                        acc_im[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(nui, g0r, acc_im[0], 0, 0, 0);
+                        acc_re[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui, g1i, acc_re[1], 0, 0, 0);
+                        acc_im[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(nui, g1r, acc_im[1], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    u_cur = u_nxt;
-                    g_cur[0] = g_nxt[0];
-                    g_cur[1] = g_nxt[1];
                 }
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
