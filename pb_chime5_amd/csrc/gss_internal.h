@@ -122,7 +122,7 @@ struct gss_ctx {
 
     // WPE tile lists (device), rebuilt when (taps, delay, D) changes
     void *wpe_tiles = nullptr;
-    int wpe_tiles_key[3] = {-1, -1, -1};
+    int wpe_tiles_key[4] = {-1, -1, -1, -1};   // taps, delay, D, correlation tile size
 
     // profiling
     bool profiling = false;

@@ -947,7 +947,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                 "wpe: taps*D=%d too large", n);
     static_assert(sizeof(CorrTile) == sizeof(UpdTile), "tile structs share one buffer");
     if (ctx->wpe_tiles_key[0] != taps || ctx->wpe_tiles_key[1] != delay ||
-        ctx->wpe_tiles_key[2] != D) {
+        ctx->wpe_tiles_key[2] != D || ctx->wpe_tiles_key[3] != corr_ts) {
         GSS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (!ctx->wpe_tiles)
             GSS_HIP_CHECK(ctx, hipMalloc(&ctx->wpe_tiles, sizeof(CorrTile) * (1024 + 4096)));
@@ -960,6 +960,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         ctx->wpe_tiles_key[0] = taps;
         ctx->wpe_tiles_key[1] = delay;
         ctx->wpe_tiles_key[2] = D;
+        ctx->wpe_tiles_key[3] = corr_ts;
     }
     CorrTile *tiles_dev = reinterpret_cast<CorrTile *>(ctx->wpe_tiles);
     UpdTile *upd_dev = reinterpret_cast<UpdTile *>(tiles_dev + 1024);

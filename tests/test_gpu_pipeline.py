@@ -462,11 +462,14 @@ def test_edge_single_class_and_two_channels(gpu_ctx):
     assert np.array_equal(np.isnan(got), np.isnan(want))
 
 
-@pytest.mark.parametrize('D,K', [(20, 4), (28, 3), (12, 6), (24, 2), (16, 3)])
+@pytest.mark.parametrize('D,K', [(20, 4), (28, 3), (12, 6), (24, 2), (16, 3), (10, 5), (4, 3), (6, 4)])
 def test_other_channel_and_class_counts(gpu_ctx, D, K):
-    """Channel counts off the tuned paths: D = 20 / 28 / 16 take the LDS-form E-step and
+    """Channel counts off the config-2 path: D = 28 / 16 / 6 take the LDS-form E-step and
     other MFMA tile counts (wpe_apply with 1 or 2 channel tiles, 3 or 4 x 8 lanes in the
-    class update), D = 12 / 24 with K = 6 / 2 the register-form E-step at its limits."""
+    class update), D = 12 / 24 with K = 6 / 2 the register-form E-step at its limits,
+    D = 20 / 10 / 4 its other instantiations (5-array sessions, one array); D <= 12 the
+    one-wave-per-sub-tile correlation, D = 4 / 6 with per-wave staging, D = 4 the
+    register-form M-step."""
     from pb_chime5_amd import synthetic
     # enough frames per unknown (T = 254, taps * D <= 56) and sensor noise 30 dB below the
     # speech (with 1 - 3 point sources on 12 - 28 microphones the spatial covariance is
@@ -499,6 +502,50 @@ def test_other_channel_and_class_counts(gpu_ctx, D, K):
         assert rel_err(got, want) < TOL_STFT_MAG
     else:
         assert (D, K) == (24, 2), (D, K, strict.mean())
+
+
+@pytest.mark.parametrize('D', [4, 12, 24])
+def test_kernel_variants_agree(gpu_ctx, D, monkeypatch):
+    """The tuned kernel variants against their plain counterparts on the same input: 16 x 16
+    vs 32 x 32 correlation tiles, 3- vs 4-product complex MFMA forms (correlation and filter
+    application), register-form vs tiled M-step (D = 4), register- vs LDS-form E-step,
+    Cholesky vs eigendecomposition model update.  Same arithmetic up to summation order."""
+    from pb_chime5_amd import ops, synthetic
+    # (frames per unknown and sensor noise as in test_other_channel_and_class_counts: a
+    # well-conditioned WPE, so that summation order does not decide the result)
+    u = synthetic.tiny(seed=40 + D, num_channels=D, num_samples=64000, num_speakers=2,
+                       context=4096, noise=3e-2)
+    cs = u.ex['start_orig']['original']
+    ce = u.ex['end']['original'] - u.ex['end_orig']['original']
+
+    def run():
+        return ops.enhance_observation(u.obs, u.activity_array, u.target_index, cs, ce, wpe=True,
+                                       wpe_taps=2, wpe_iterations=2, bss_iterations=5,
+                                       debug=True)
+    base, bdet = run()
+    # the beamformer is compared where the noise PSD matrix is not singular to rounding
+    # (few point sources on many microphones, see test_other_channel_and_class_counts)
+    dm = np.sum(np.delete(bdet['posterior'], u.target_index, axis=0), axis=0)
+    cond = np.linalg.cond(oracle.get_power_spectral_density_matrix(bdet['Obs'].transpose(2, 0, 1),
+                                                                   dm.T))
+    good = cond < 1e8
+    assert good.mean() > 0.05, good.mean()
+    for env in ({'GSS_CORR_TS': '2' if D <= 12 else '1'}, {'GSS_CORR_4M': '1', 'GSS_APPLY_4M': '1'},
+                {'GSS_MSTEP_TILED': '1'}, {'GSS_ESTEP_LDS': '1'}, {'GSS_FORCE_EIGH': '1'},
+                {'GSS_CORR_NW': '2'}, {'GSS_APPLY_NWV': '2'}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        other, odet = run()
+        for k in env:
+            monkeypatch.delenv(k)
+        errs = (rel_err(odet['Obs'], bdet['Obs']), np.max(np.abs(odet['posterior'] - bdet['posterior'])),
+                rel_err(odet['X_hat'][:, good], bdet['X_hat'][:, good]))
+        print(D, env, errs)
+        # the WPE solve amplifies rounding by cond(R) (1.6e-6 against the oracle in the worst
+        # bin of this kind of scene), the EM by another two orders of magnitude
+        assert errs[0] < 1e-5 and errs[1] < 1e-3 and errs[2] < TOL_STFT_MAG, (env, errs)
+        if good.all():
+            assert rel_err(other, base) < TOL_STFT_MAG, (env, rel_err(other, base))
 
 
 def test_unsupported_sizes_fail_loudly(gpu_ctx):
