@@ -64,10 +64,30 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Sum over the 64 lanes (all active) on the DPP network (row shifts, then row broadcasts; the
+// classic GCN reduction) instead of six ds_bpermute round trips per value: 7 VALU steps, no
+// LDS crossbar.  The total forms in lane 63 and is handed to every lane through an SGPR.
+// It matters where many values are reduced back to back (register-form M-step: 80 sums per
+// wave, a third of the kernel with the butterfly).
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_shifted(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, BANK_MASK, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, BANK_MASK, true);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    double s = v + dpp_shifted<0x111, 0xf, 0xf>(v);      // row_shr:1
+    s += dpp_shifted<0x112, 0xf, 0xf>(v);                // row_shr:2
+    s += dpp_shifted<0x113, 0xf, 0xf>(v);                // row_shr:3
+    s += dpp_shifted<0x114, 0xf, 0xe>(s);                // row_shr:4, banks 1-3
+    s += dpp_shifted<0x118, 0xf, 0xc>(s);                // row_shr:8, banks 2-3
+    s += dpp_shifted<0x142, 0xa, 0xf>(s);                // row_bcast:15 into rows 1, 3
+    s += dpp_shifted<0x143, 0xc, 0xf>(s);                // row_bcast:31 into rows 2, 3
+    const unsigned long long u = __double_as_longlong(s);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, 63);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
