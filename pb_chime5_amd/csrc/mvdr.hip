@@ -244,20 +244,29 @@ __global__ __launch_bounds__(64) void mvdr_solve_kernel(
         Wf[it] = wv;
     }
     __syncthreads();
-    // SNR terms per reference channel r: w_r^H Phi_X w_r and w_r^H Phi_N w_r
+    // SNR terms per reference channel r: w_r^H Phi_X w_r and w_r^H Phi_N w_r.  The products
+    // T_X = Phi_X W (-> right half of aug) and T_N = Phi_N W (-> JA) are spread over the whole
+    // wave; the sums over e and then over d run in the same order as one lane per r would
+    // take them.
+    for (int it = lane; it < D * D; it += 64) {
+        const int d = it / D, r = it - d * D;
+        cplx tx = c_make(0.0, 0.0), tn = c_make(0.0, 0.0);
+        for (int e = 0; e < D; ++e) {
+            const cplx we = aug[e * W2 + r];
+            c_fma(tx, PhiX[d * D + e], we);
+            c_fma(tn, PhiN[d * D + e], we);
+        }
+        aug[d * W2 + D + r] = tx;
+        JA[d * m + r] = tn;
+    }
+    __syncthreads();
     if (lane < D) {
         const int r = lane;
         cplx num = c_make(0.0, 0.0), den = c_make(0.0, 0.0);
         for (int d = 0; d < D; ++d) {
-            cplx tx = c_make(0.0, 0.0), tn = c_make(0.0, 0.0);
-            for (int e = 0; e < D; ++e) {
-                const cplx we = aug[e * W2 + r];
-                c_fma(tx, PhiX[d * D + e], we);
-                c_fma(tn, PhiN[d * D + e], we);
-            }
             const cplx wd = aug[d * W2 + r];
-            c_cfma(num, wd, tx);
-            c_cfma(den, wd, tn);
+            c_cfma(num, wd, aug[d * W2 + D + r]);
+            c_cfma(den, wd, JA[d * m + r]);
         }
         snr[((int64_t)f * D + r) * 2] = num;
         snr[((int64_t)f * D + r) * 2 + 1] = den;
