@@ -455,6 +455,7 @@ __global__ __launch_bounds__(256) void mvdr_apply_kernel(
     cplx *__restrict__ Xhat, int32_t *__restrict__ ref_out) {
     __shared__ cplx w[GSS_MAX_CHANNELS];
     __shared__ cplx t1[GSS_MAX_CHANNELS];
+    __shared__ cplx t2[GSS_MAX_CHANNELS];
     __shared__ double s_norm;
     const int f = blockIdx.y, tid = threadIdx.x;
     const int r = ref[0];
@@ -467,15 +468,16 @@ __global__ __launch_bounds__(256) void mvdr_apply_kernel(
             cplx v = c_make(0.0, 0.0);
             for (int e = 0; e < D; ++e) c_fma(v, PhiN[tid * D + e], w[e]);
             t1[tid] = v;   // Phi_N w
+            cplx u = c_make(0.0, 0.0);   // (w^H Phi_N)_a = sum_d conj(w_d) Phi_N[d][a], a = tid
+            for (int d = 0; d < D; ++d) c_cfma(u, w[d], PhiN[d * D + tid]);
+            t2[tid] = u;
         }
         __syncthreads();
         if (tid == 0) {
             // nominator = w^H Phi_N Phi_N w ; denominator = w^H Phi_N w
             cplx nom = c_make(0.0, 0.0), den = c_make(0.0, 0.0);
             for (int a = 0; a < D; ++a) {
-                cplx u = c_make(0.0, 0.0);   // (w^H Phi_N)_a = sum_d conj(w_d) Phi_N[d][a]
-                for (int d = 0; d < D; ++d) c_cfma(u, w[d], PhiN[d * D + a]);
-                c_fma(nom, u, t1[a]);
+                c_fma(nom, t2[a], t1[a]);
                 c_cfma(den, w[a], t1[a]);
             }
             const double n = sqrt(hypot(nom.x, nom.y));   // |sqrt(z)|
@@ -594,7 +596,7 @@ int mvdr_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double 
     }
     {
         GSS_PROF(ctx, "mvdr_apply");
-        const int chunk = 1024;
+        const int chunk = 256;
         hipLaunchKernelGGL(mvdr_apply_kernel, dim3((unsigned)((T + chunk - 1) / chunk), F),
                            dim3(256), 0, ctx->stream, Y, W, Phi, ref, F, T, D, ban, chunk, Xhat,
                            ref_channel);

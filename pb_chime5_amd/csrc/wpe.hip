@@ -25,27 +25,46 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 namespace {
 
 // ------------------------------------------------------------------ power
-__global__ __launch_bounds__(256) void wpe_power_kernel(const cplx *__restrict__ X, int64_t T,
-                                                        int D, double *__restrict__ w) {
-    __shared__ double red[4];
-    const int f = blockIdx.x;
+// One workgroup per frequency (the maximum over the frames comes before the inversion).
+// Frames are taken 256 at a time: the 256 x D squared magnitudes are read with coalesced
+// loads (consecutive lanes, consecutive bins -- a lane walking its own frame touches 64
+// cache lines per load), parked in LDS, and summed per frame from there.
+constexpr int POW_FRAMES = 256;
+__global__ __launch_bounds__(POW_FRAMES) void wpe_power_kernel(const cplx *__restrict__ X,
+                                                               int64_t T, int D,
+                                                               double *__restrict__ w) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *ps = reinterpret_cast<double *>(smem);      // POW_FRAMES * (D + 1)
+    __shared__ double red[POW_FRAMES / 64];
+    const int f = blockIdx.x, tid = threadIdx.x;
     const cplx *Xf = X + (int64_t)f * T * D;
     double *wf = w + (int64_t)f * T;
+    const int DP = D + 1;                                // odd-ish stride against bank conflicts
     double mx = 0.0;
-    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
-        const cplx *y = Xf + t * D;
-        double p = 0.0;
-        for (int d = 0; d < D; ++d) p += c_abs2(y[d]);
-        p = p / (double)D;
-        wf[t] = p;
-        mx = fmax(mx, p);
+    for (int64_t t0 = 0; t0 < T; t0 += POW_FRAMES) {
+        const int nfr = (int)min((int64_t)POW_FRAMES, T - t0);
+        const int total = nfr * D;
+        const cplx *src = Xf + t0 * D;
+        __syncthreads();
+        for (int idx = tid; idx < total; idx += POW_FRAMES) {
+            const int fr = idx / D, d = idx - fr * D;
+            ps[fr * DP + d] = c_abs2(src[idx]);
+        }
+        __syncthreads();
+        if (tid < nfr) {
+            double p = 0.0;
+            for (int d = 0; d < D; ++d) p += ps[tid * DP + d];
+            p = p / (double)D;
+            wf[t0 + tid] = p;
+            mx = fmax(mx, p);
+        }
     }
     mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
     __syncthreads();
     mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
     const double eps = 1e-10 * mx;
-    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) wf[t] = 1.0 / fmax(wf[t], eps);
+    for (int64_t t = tid; t < T; t += POW_FRAMES) wf[t] = 1.0 / fmax(wf[t], eps);
 }
 
 // ------------------------------------------------------------------ correlation (MFMA)
@@ -1025,7 +1044,13 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         const cplx *cur = it == 0 ? Y : X;
         {
             GSS_PROF(ctx, "wpe_power");
-            hipLaunchKernelGGL(wpe_power_kernel, dim3(F), dim3(256), 0, ctx->stream, cur, T, D, w);
+            const size_t pow_lds = sizeof(double) * POW_FRAMES * (D + 1);
+            if (pow_lds > 64 * 1024)
+                GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(wpe_power_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)pow_lds));
+            hipLaunchKernelGGL(wpe_power_kernel, dim3(F), dim3(POW_FRAMES), pow_lds, ctx->stream,
+                               cur, T, D, w);
             GSS_LAUNCH_CHECK(ctx, "wpe_power_kernel");
         }
         {
