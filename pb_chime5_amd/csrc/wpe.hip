@@ -420,12 +420,23 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(cplx *__restrict__ R,
     if (!xcd_group_map((npanel + 3) / 4, F, f, grp)) return;
     cplx *A = R + (int64_t)f * n * n;
     cplx *Z = P + (int64_t)f * n * D;
-    for (int idx = tid; idx < CH_NB * CH_NB; idx += blockDim.x) {
+    // W block -> LDS: all 9 loads of a thread in flight before the first store
+    constexpr int WL = CH_NB * CH_NB / 256;
+    static_assert(WL * 256 == CH_NB * CH_NB, "block size");
+    cplx wv[WL];
+#pragma unroll
+    for (int s = 0; s < WL; ++s) {
+        const int idx = tid + 256 * s;
         const int i = idx / CH_NB, k = idx - i * CH_NB;
-        cplx v = c_make(0.0, 0.0);
-        if (i < nb && k <= i) v = A[(int64_t)(j0 + i) * n + j0 + k];
-        Ud[i * UD_LD + k] = v;
-        if (k == i) dinv[i] = v.x > 0.0 ? 1.0 / v.x : 0.0;
+        wv[s] = c_make(0.0, 0.0);
+        if (i < nb && k <= i) wv[s] = A[(int64_t)(j0 + i) * n + j0 + k];
+    }
+#pragma unroll
+    for (int s = 0; s < WL; ++s) {
+        const int idx = tid + 256 * s;
+        const int i = idx / CH_NB, k = idx - i * CH_NB;
+        Ud[i * UD_LD + k] = wv[s];
+        if (k == i) dinv[i] = wv[s].x > 0.0 ? 1.0 / wv[s].x : 0.0;
     }
     __syncthreads();
     const int ct = grp * 4 + (tid >> 6);
