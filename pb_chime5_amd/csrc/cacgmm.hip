@@ -447,7 +447,11 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
     if (SRC_FDT && PREFETCH) prefetch(c0);
     for (int64_t t0 = c0; t0 < c1; t0 += EM_TILE) {
         __syncthreads();
-        if (SRC_FDT && PREFETCH) {
+        if (SRC_FDT) {
+            // Y is already the (F, D, T) unit-normalised copy: rows are contiguous.  Without
+            // PREFETCH the tile is requested here -- all loads of a thread in flight before
+            // its first LDS store (one load per trip of a loop is a chain of round trips).
+            if (!PREFETCH) prefetch(t0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int d = g + 4 * j;
@@ -459,16 +463,9 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
                 if (idx < KW * EM_TILE) wk[idx] = wpre[j];
             }
             __syncthreads();
-            if (t0 + EM_TILE < c1) prefetch(t0 + EM_TILE);
+            if (PREFETCH && t0 + EM_TILE < c1) prefetch(t0 + EM_TILE);
         } else {
-            if (SRC_FDT) {
-                // Y is already the (F, D, T) unit-normalised copy: rows are contiguous
-                const cplx *src = Y + (int64_t)f * D * T;
-                for (int d = g; d < D; d += 4)
-                    ys[d * EM_TS + tl] = t0 + tl < c1 ? src[(int64_t)d * T + t0 + tl] : c_make(0.0, 0.0);
-            } else {
-                load_tile<NORMALISE>(Yf, D, t0, c1, tl, g, ys, scratch);
-            }
+            load_tile<NORMALISE>(Yf, D, t0, c1, tl, g, ys, scratch);
             for (int idx = tid; idx < KW * EM_TILE; idx += blockDim.x) {
                 const int k = idx / EM_TILE, j = idx - k * EM_TILE;
                 wk[idx] = t0 + j < c1 ? Wf[(int64_t)k * T + t0 + j] : 0.0;
@@ -1001,7 +998,10 @@ int launch_mstep(gss_ctx *ctx, const EmArgs &a, const cplx *Yn, int F) {
         return GSS_OK;
     }
     if (Yn) {
-        static const int pf_max_d = getenv("GSS_MSTEP_PREFETCH_D") ? atoi(getenv("GSS_MSTEP_PREFETCH_D")) : 20;
+        // (cross-tile prefetch against loading the tile in place, ms per launch at T = 2169:
+        // D = 10 0.113 / 0.120, D = 12 0.122 / 0.124, D = 20 0.219 / 0.207; D = 24, T = 941:
+        // 0.130 / 0.118)
+        static const int pf_max_d = getenv("GSS_MSTEP_PREFETCH_D") ? atoi(getenv("GSS_MSTEP_PREFETCH_D")) : 12;
         if (a.D <= pf_max_d) {
             GSS_TRY(raise_lds_limit(ctx, wcov_kernel<K, false, true, true>, lds));
             hipLaunchKernelGGL((wcov_kernel<K, false, true, true>), dim3(xcd_grid(a.nch, F)),
