@@ -63,24 +63,53 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_kernel(
     const int F = size / 2 + 1;
 
     if (threadIdx.x == 0) *nz = 0u;
-    for (int i = threadIdx.x; i < size / 2; i += blockDim.x) tw[i] = twiddle[i];
+    // Loads in batches of LB per thread, all in flight before the first LDS store: a
+    // load - store loop is a chain of dependent round trips (three per trip here), and a
+    // workgroup lives for little more than its ten FFT passes.
+    constexpr int LB = 8;
+    for (int base = 0; base < size / 2; base += 2 * FFT_THREADS) {
+        cplx tv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = base + threadIdx.x + j * FFT_THREADS;
+            tv[j] = i < size / 2 ? twiddle[i] : c_make(0.0, 0.0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = base + threadIdx.x + j * FFT_THREADS;
+            if (i < size / 2) tw[i] = tv[j];
+        }
+    }
     __syncthreads();
     const int64_t n0 = t * shift - pad;
     unsigned mine = 0u;
-    for (int idx = threadIdx.x; idx < PAIRS * size; idx += blockDim.x) {
-        const int pr = idx / size;
-        const int i = idx - pr * size;
-        const int64_t n = n0 + i;
-        const int da = d0 + 2 * pr, db = da + 1;
-        double va = 0.0, vb = 0.0;
-        if (n >= 0 && n < N) {
-            const double w = window[i];
-            if (da < D) va = ((double)x[(int64_t)da * N + n] * in_scale) * w;
-            if (db < D) vb = ((double)x[(int64_t)db * N + n] * in_scale) * w;
+    for (int base = 0; base < PAIRS * size; base += LB * FFT_THREADS) {
+        double wv[LB];
+        TIn ra[LB], rb[LB];
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+            const int idx = base + threadIdx.x + j * FFT_THREADS;
+            const int pr = idx / size;
+            const int i = idx - pr * size;
+            const int64_t n = n0 + i;
+            const int da = d0 + 2 * pr, db = da + 1;
+            const bool in = idx < PAIRS * size && n >= 0 && n < N;
+            wv[j] = in ? window[i] : 0.0;
+            ra[j] = in && da < D ? x[(int64_t)da * N + n] : (TIn)0;
+            rb[j] = in && db < D ? x[(int64_t)db * N + n] : (TIn)0;
         }
-        s[pr * size + bitrev(i, log2n)] = c_make(va, vb);
-        if (va != 0.0) mine |= 1u << (2 * pr);
-        if (vb != 0.0) mine |= 1u << (2 * pr + 1);
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+            const int idx = base + threadIdx.x + j * FFT_THREADS;
+            if (idx >= PAIRS * size) continue;
+            const int pr = idx / size;
+            const int i = idx - pr * size;
+            const double va = ((double)ra[j] * in_scale) * wv[j];
+            const double vb = ((double)rb[j] * in_scale) * wv[j];
+            s[pr * size + bitrev(i, log2n)] = c_make(va, vb);
+            if (va != 0.0) mine |= 1u << (2 * pr);
+            if (vb != 0.0) mine |= 1u << (2 * pr + 1);
+        }
     }
     if (mine) atomicOr(nz, mine);
     __syncthreads();
