@@ -642,6 +642,19 @@ __device__ inline void chol_backsolve_body(const cplx *A, cplx *Z, int n, int D,
                             c_make(acc_re[b][reg], acc_im[b][reg]);
             }
             __syncthreads();
+            // W_J fragments for the product below, all requested at once (loaded inside its
+            // k loop, each of the up to 12 steps waited for a round trip)
+            cplx wall[CH_NB / 4];
+            if (a < 3) {
+                const int i = 16 * a + li;
+#pragma unroll
+                for (int ks = 0; ks < CH_NB / 4; ++ks) {
+                    const int k = 4 * ks + lk;
+                    wall[ks] = c_make(0.0, 0.0);
+                    if (ks >= 4 * a && i < nb && k < nb && k >= i)
+                        wall[ks] = A[(int64_t)(j0 + k) * n + j0 + i];
+                }
+            }
             if (a < 3) {
                 // ---- G_J = W^H S :  out[i][d] = sum_{k >= i} conj(W[k][i]) S[k][d],
                 // W[k][i] (k > i) sits at A[j0+k][j0+i], W[i][i] = 1 / U[i][i]
@@ -652,14 +665,16 @@ __device__ inline void chol_backsolve_body(const cplx *A, cplx *Z, int n, int D,
                     acc_im[b] = (v4d){0.0, 0.0, 0.0, 0.0};
                 }
                 const int i = 16 * a + li;
-                for (int ks = 4 * a; ks < (nb + 3) / 4; ++ks) {
+#pragma unroll
+                for (int ks = 0; ks < CH_NB / 4; ++ks) {
+                    if (ks < 4 * a || ks >= (nb + 3) / 4) continue;     // wave uniform
                     const int k = 4 * ks + lk;
                     cplx w = c_make(0.0, 0.0);
                     if (i < nb && k < nb) {
                         if (k > i) {
-                            w = A[(int64_t)(j0 + k) * n + j0 + i];
+                            w = wall[ks];
                         } else if (k == i) {
-                            const double d = A[(int64_t)(j0 + i) * n + j0 + i].x;
+                            const double d = wall[ks].x;
                             w = c_make(d > 0.0 ? 1.0 / d : 0.0, 0.0);
                         }
                     }
