@@ -970,22 +970,31 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     if (const char *e = getenv("GSS_CORR_TS")) corr_ts = atoi(e) == 1 ? 1 : 2;
     const int ntiles = corr_tiles(n, D, c, 16 * corr_ts, tiles);
     // trailing-update tiles: 16 x 16, every tile that reaches the upper triangle (larger
-    // register tiles -- 2 x 2, 2 x 3, 3 x 3 MFMA tiles per wave -- measured slower: the
-    // update is bound by its traffic and wants many small workgroups in flight)
+    // register tiles -- 2 x 2, 1 x 2, 2 x 1 MFMA tiles per wave -- measured slower: the update
+    // is bound by the read-modify-write of the trailing matrix and wants many small
+    // workgroups in flight).  To halve that traffic the block columns are taken in pairs:
+    // after an even block J only block row J + 1 is updated (K = 48, panel J), after an odd
+    // block J everything below it is updated once with both panels J - 1 and J (K = 96).
     constexpr int tm16 = 16, tn16 = 16;
     std::vector<UpdTile> upd;
-    std::vector<int> upd_start, upd_count;
+    std::vector<int> upd_start, upd_count, upd_j0, upd_k;
     {
         const int nblk = (n + CH_NB - 1) / CH_NB;
+        static const bool paired = getenv("GSS_UPD_UNPAIRED") == nullptr;
         for (int J = 0; J < nblk; ++J) {
             upd_start.push_back((int)upd.size());
             const int rs = (J + 1) * CH_NB;
-            for (int r0 = rs; r0 < n; r0 += tm16) {
+            const bool narrow = paired && J % 2 == 0;
+            const int r_end = narrow ? std::min(rs + CH_NB, n) : n;
+            for (int r0 = rs; r0 < r_end; r0 += tm16) {
                 for (int c0 = rs; c0 < n; c0 += tn16)
                     if (c0 + tn16 > r0) upd.push_back({r0, c0, 0, 0});
                 for (int cc = 0; cc < D; cc += tn16) upd.push_back({r0, cc, 1, 0});
             }
             upd_count.push_back((int)upd.size() - upd_start.back());
+            const bool wide = paired && J % 2 == 1;
+            upd_j0.push_back(wide ? (J - 1) * CH_NB : J * CH_NB);
+            upd_k.push_back(wide ? 2 * CH_NB : CH_NB);
         }
     }
     GSS_REQUIRE(ctx, ntiles <= 1024 && upd.size() <= 4096, GSS_ERR_UNSUPPORTED,
@@ -1109,7 +1118,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                     const dim3 g(xcd_grid((nupd + 3) / 4, F)), b(256);
                     const UpdTile *tl = upd_dev + upd_start[J];
                     hipLaunchKernelGGL((chol_update_kernel<1, 1, true>), g, b, 0, ctx->stream, R, P,
-                                       F, n, D, j0, nb, tl, nupd);
+                                       F, n, D, upd_j0[J], std::min(upd_k[J], n - upd_j0[J]), tl, nupd);
                     GSS_LAUNCH_CHECK(ctx, "chol_update_kernel");
                 }
             }
