@@ -743,7 +743,7 @@ __global__ __launch_bounds__(64 * NWV) void wpe_apply_kernel(const cplx *__restr
     const int64_t fr0 = t0 - c;
     // window -> LDS, 8 loads in flight per thread (one load per trip is a chain of
     // dependent round trips as long as the whole k loop)
-    constexpr int PRE = 8, NT = 64 * NWV;
+    constexpr int PRE = 14, NT = 64 * NWV;
     const int total = frames_lds * D;
     for (int base = 0; base < total; base += NT * PRE) {
         cplx v[PRE];
