@@ -295,14 +295,18 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_kernel(
 // the upper triangle with the right-hand sides carried along ([R | P] -> [U | Z],
 // Z = U^-H P), then blocked back substitution U G = Z (G overwrites P).
 // Per block column J of CH_NB = 48 rows:
-//   chol_diag    grid (F), one wave:   factor the 48 x 48 diagonal block in LDS and
-//                                      invert it: W = U_JJ^-H (lower triangular) is
-//                                      kept in the unused strictly-lower triangle
+//   chol_diag    grid (F), 256 threads: factor the 48 x 48 diagonal block and invert it in
+//                                      one register-resident sweep: W = U_JJ^-H (lower
+//                                      triangular) is kept in the unused strictly-lower
+//                                      triangle
 //   chol_trsm    XCD grid (chunks x F): row panel  U_J = W A_J  (and Z_J = W P_J)
 //   chol_update  XCD grid (tiles x F): trailing update C -= U_J^H U_J with the f64
-//                                      MFMA, one 48 x 48 tile per wave, accumulators
+//                                      MFMA, one 16 x 16 tile per wave, accumulators
 //                                      loaded from / stored to global memory in
-//                                      fragment layout, operands double-buffered
+//                                      fragment layout, operands double-buffered; block
+//                                      columns in pairs (see wpe_run): after an even block
+//                                      only the next block row, after an odd one everything
+//                                      below with both panels (K = 96)
 //   chol_backsolve grid (F):           G_J = W^H (Z_J - U_J,>J G_>J), J descending
 // A non-positive pivot (exactly singular system, e.g. an all-zero channel) zeroes
 // that row, which reproduces the minimum-norm lstsq fallback of stable_solve
