@@ -128,7 +128,7 @@ def _reverberant(rng, D, T, F, taps=6):
 
 @pytest.mark.parametrize('D,T,F,taps,delay,iters', [
     (4, 60, 9, 3, 2, 2), (2, 40, 5, 1, 0, 1), (5, 131, 7, 4, 3, 3), (24, 941, 2, 10, 2, 3),
-    (12, 500, 3, 10, 2, 2), (3, 60, 4, 10, 2, 1), (29, 700, 1, 10, 2, 1)])
+    (12, 500, 3, 10, 2, 2), (3, 60, 4, 10, 2, 1), (29, 700, 1, 10, 2, 1), (32, 300, 3, 2, 2, 2)])
 def test_wpe_matches_oracle(gpu_ctx, D, T, F, taps, delay, iters):
     from pb_chime5_amd import ops
     rng = np.random.default_rng(D * T)
