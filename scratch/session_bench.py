@@ -9,7 +9,7 @@ root = Path(tempfile.mkdtemp(prefix='sess_'))
 t = time.time()
 jp = write_chime5_corpus(root / 'corpus', seconds=90.0, utts_per_speaker=4, num_redacted=1, seed=5)
 print('corpus written in', round(time.time() - t, 1), 's')
-for inflight in (1, 2, 2):
+for inflight in (1, 2, 3, 3, 4):
     enh = get_enhancer(database_path=str(jp), multiarray=True, context_samples=240000)
     enh.inflight = inflight
     it = enh.get_iterator('S02')
