@@ -1,27 +1,43 @@
 """Headline benchmark: utterance-seconds enhanced per second (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3]
+
+``--gpus N`` with N > 1 may be started either way:
+
+    python bench.py --gpus N ...                       (spawns its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the whole hot path (STFT -> WPE -> CACGMM EM -> MVDR+BAN ->
-iSTFT) over one synthetic utterance of BASELINE.json configs[1]: 24 microphones
-(6 arrays x 4), 15 s at 16 kHz, 4 speakers + noise class, WPE taps 10 / delay 2 /
-3 iterations, 20 EM iterations (+1 predict), MVDR-Souden with BAN.  The time-domain
-observation and the activity are resident in HBM before the timed region starts;
-every step runs the full pipeline on them (nothing is cached between steps).
+One rank per GPU; when the node has fewer GPUs than ranks the ranks share devices
+(LOCAL_RANK % device count) and the host-side rendezvous uses gloo instead of RCCL.
+Utterances are independent, so there is NO data-path collective: torch.distributed
+carries the rendezvous, the barriers around the timed regions, the max-over-ranks
+of the elapsed time and (through its TCP store) the shared work counter of
+``pb_chime5_amd.parallel.split_managed`` -- the replacement of the reference's
+``dlp_mpi.split_managed`` (/root/reference/pb_chime5/core.py:381).
 
-Multi-GPU: utterances are independent, so each rank (one per GPU) enhances its own
-utterances; there is no data-path collective.  torch.distributed is used only for
-the launch rendezvous, the barriers around the timed region and the max-over-ranks
-of the elapsed time.  scaling = "weak" (work per GPU is fixed).
+--config 2 (default; BASELINE.json configs[1], the configuration the metric is quoted on)
+    A "step" is one pass of the whole hot path (STFT -> WPE -> CACGMM EM -> MVDR+BAN ->
+    iSTFT) over one synthetic 24-microphone 15 s utterance whose samples and activity
+    are resident in HBM when the timed region starts (`value`).  Every rank times its
+    own K steps ("weak" scaling).  Besides `value` the line carries
+      value_incl_pcie   the session driver's mode: two utterances in flight per GPU,
+                        PCM16 upload (H2D) and result download (D2H) inside the wall clock
+      configs           in-process timings of the other BASELINE configs (1, one dev-shaped
+                        item of 3, 5; 4 = "not run: corpus unavailable")
+      config3_sharded   BASELINE configs[2]: 512 dev-shaped utterances pulled by all ranks
+                        from the shared longest-first queue, 2 in flight per GPU, H2D/D2H timed
+      em_loop           EM-loop time per iteration against the HBM and f64-VALU roofs for
+                        24 channels and for one array (4 channels)
+      roofline          the dominant kernel, timed with HIP events inside the timed region
+      cpu_baseline      the NumPy oracle on W = physical cores - 1 worker processes
+    ``--only-headline`` skips everything but `value` / `roofline` / `kernels` (the command
+    the rocprofv3 summaries under profiles/ are taken with: back-to-back launches of one
+    stream and one shape only).
 
-Rank 0 prints ONE JSON line with the contract fields plus
-  roofline      for the kernel that dominates device time (HIP-event timing of every
-                launch on the stream the kernels run on, collected over the timed
-                region), priced with the algorithmic work of pb_chime5_amd/roofline.py
-  cpu_baseline  the NumPy oracle (float64, single thread, per-frequency loops like
-                the reference) timed on a bounded sample of the same workload.
+--config 3
+    The sharded session alone: `value` = sum of utterance seconds / wall clock over all
+    ranks, "strong" scaling (the 512 items are fixed), steps = items.
 """
 import argparse
 import json
@@ -37,113 +53,368 @@ sys.path.insert(0, str(REPO))
 
 WORKLOAD = dict(num_channels=24, seconds=15.0, num_speakers=4, wpe_taps=10, wpe_delay=2,
                 wpe_iterations=3, bss_iterations=20, bss_iterations_post=1)
+PROFILE_STEPS = 3
+SR = 16000
 
 
-def cpu_baseline(utt, sample_bins=24):
-    """Time the oracle (kind 'port') on one host core: full STFT / masks / MVDR /
-    iSTFT, WPE + EM on `sample_bins` of the 513 frequency bins (the reference loops
-    over frequencies in Python, so cost is linear in the number of bins), then
-    extrapolate to 513 bins."""
+# ----------------------------------------------------------------------------------
+# CPU baseline (the oracle; test / bench infrastructure, never on the product path)
+# ----------------------------------------------------------------------------------
+def _limit_threads():
     for var in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):
         os.environ[var] = '1'
     try:
         from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=1)
+        threadpool_limits(limits=1)
     except Exception:
-        limiter = None
+        pass
+
+
+def _cpu_worker(job):
+    """One worker process of the CPU baseline = one rank of `mpiexec -np W+1`
+    (/root/reference/README.md:108-111), numeric libraries pinned to one thread like
+    /root/reference/pb_chime5/__init__.py:3-14.  Enhances whole utterances with the
+    oracle: config 1 in full; config 2 with WPE + EM on a sample of the frequency bins
+    (the reference loops over frequencies in Python, cost is linear in the bins) and
+    everything else in full, extrapolated to 513 bins."""
+    _limit_threads()
     sys.path.insert(0, str(REPO / 'oracle'))
     import gss_oracle as oracle
+    path, sample_bins, n_cfg1 = job
+    data = np.load(path)
+    out = {}
+    # ---- config 1: full utterances
+    obs, act = data['obs1'], data['act1'].astype(bool)
+    ex1 = dict(start={'original': 0}, start_orig={'original': 0},
+               end_orig={'original': obs.shape[1]}, end={'original': obs.shape[1]})
+    t0 = time.perf_counter()
+    for _ in range(n_cfg1):
+        oracle.enhance_observation(obs, act, 0, ex1, wpe=False, bss_iterations=5,
+                                   bss_iterations_post=1)
+    out['cfg1_s'] = (time.perf_counter() - t0) / n_cfg1
+    # ---- config 2: bin-sampled
+    obs, act = data['obs2'], data['act2'].astype(bool)
+    ctx = int(data['ctx2'])
+    ex2 = dict(start={'original': 0}, start_orig={'original': ctx},
+               end_orig={'original': obs.shape[1] - ctx}, end={'original': obs.shape[1]})
     F = 513
     bins = np.linspace(0, F - 1, sample_bins).astype(int)
     t0 = time.perf_counter()
-    Obs = oracle.stft(utt.obs)
-    act_f = oracle.activity_time_to_frequency(utt.activity_array, 1024, 256, True)
-    t_stft = time.perf_counter() - t0
+    Obs = oracle.stft(obs)
+    act_f = oracle.activity_time_to_frequency(act, 1024, 256, True)
+    t_full = time.perf_counter() - t0
     t0 = time.perf_counter()
     Xs = oracle.wpe_block(Obs[..., bins], WORKLOAD['wpe_taps'], WORKLOAD['wpe_delay'],
                           WORKLOAD['wpe_iterations'])
-    t_wpe = time.perf_counter() - t0
-    t0 = time.perf_counter()
     post = oracle.gss_block(Xs, act_f, WORKLOAD['bss_iterations'],
                             WORKLOAD['bss_iterations_post'])
-    t_em = time.perf_counter() - t0
-    # beamformer + istft at full size, on stand-in masks of the right shape
-    masks = np.repeat(post[..., :1], F, axis=-1)
+    t_bins = time.perf_counter() - t0
+    masks = np.repeat(post[..., :1], F, axis=-1)       # stand-in masks of the full shape
     t0 = time.perf_counter()
-    sf, ef = oracle.start_end_context_frames(utt.ex, 1024, 256, True)
+    sf, ef = oracle.start_end_context_frames(ex2, 1024, 256, True)
     masks[:, :sf] = 0
     masks[:, -ef:] = 0
-    tm = masks[utt.target_index]
-    dm = np.sum(np.delete(masks, utt.target_index, axis=0), axis=0)
-    X_hat = oracle.beamform_mvdr_souden_from_masks(Obs, tm, dm, ban=True)
+    X_hat = oracle.beamform_mvdr_souden_from_masks(
+        Obs, masks[0], np.sum(masks[1:], axis=0), ban=True)
     oracle.istft(X_hat)
-    t_bf = time.perf_counter() - t0
-    if limiter is not None:
-        limiter.restore_original_limits()
-    scale = F / float(sample_bins)
-    total = t_stft + t_bf + scale * (t_wpe + t_em)
+    t_full += time.perf_counter() - t0
+    out['cfg2_full_part_s'] = t_full
+    out['cfg2_bins_part_s'] = t_bins
+    out['cfg2_s'] = t_full + t_bins * F / float(sample_bins)
+    return out
+
+
+def _host_cpu():
+    model, phys = None, set()
+    try:
+        pid = cid = None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name') and model is None:
+                model = line.split(':', 1)[1].strip()
+            elif line.startswith('physical id'):
+                pid = line.split(':', 1)[1].strip()
+            elif line.startswith('core id'):
+                cid = line.split(':', 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        logical = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    physical = min(len(phys), logical) if phys else logical
+    # a container may be limited to fewer CPUs than it can see (cgroup v2 cpu.max / v1 quota)
+    quota = None
+    try:
+        q, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    mem_gb = None
+    try:
+        for line in open('/proc/meminfo'):
+            if line.startswith('MemAvailable'):
+                mem_gb = int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return model or 'unknown', physical, logical, mem_gb, quota
+
+
+def cpu_baseline(utt2, sample_bins=24, max_workers=None):
+    """the NumPy oracle (kind 'port') on W = physical cores - 1
+    single-threaded worker processes, every worker enhancing whole utterances at the same
+    time (so the figure includes what the cores cost each other in memory bandwidth)."""
+    import multiprocessing as mp
+    import tempfile
+    from pb_chime5_amd import synthetic
+    model, physical, logical, mem_gb, quota = _host_cpu()
+    usable = physical if quota is None else max(1, min(physical, int(quota)))
+    W = max(usable - 1, 1)
+    if mem_gb is not None:                       # ~1.5 GB per worker at config 2
+        W = max(1, min(W, int(mem_gb / 2.0)))
+    if max_workers:
+        W = max(1, min(W, max_workers))
+    utt1 = synthetic.config1()
+    saved = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS',
+                                             'OPENBLAS_NUM_THREADS')}
+    tmp = tempfile.NamedTemporaryFile(suffix='.npz', delete=False)
+    tmp.close()
+    try:
+        np.savez(tmp.name, obs1=utt1.obs, act1=utt1.activity_array.astype(np.uint8),
+                 obs2=utt2.obs, act2=utt2.activity_array.astype(np.uint8),
+                 ctx2=utt2.ex['start_orig']['original'])
+        for k in saved:
+            os.environ[k] = '1'                  # inherited by the spawned workers
+        t0 = time.perf_counter()
+        # (an executor, not mp.Pool: a worker that dies raises BrokenProcessPool here
+        # instead of being respawned for ever)
+        from concurrent.futures import ProcessPoolExecutor
+        with ProcessPoolExecutor(W, mp_context=mp.get_context('spawn')) as pool:
+            futures = [pool.submit(_cpu_worker, (tmp.name, sample_bins, 2)) for _ in range(W)]
+            res = [f.result(timeout=600) for f in futures]
+        wall = time.perf_counter() - t0
+    finally:
+        os.unlink(tmp.name)
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    cfg1 = float(np.mean([r['cfg1_s'] for r in res]))
+    cfg2 = float(np.mean([r['cfg2_s'] for r in res]))
     return {
-        'value': utt.seconds / total, 'unit': 'utterance-seconds/s', 'cores': 1,
-        'kind': 'port',
-        'sample': (f'one config-2 utterance; WPE+EM on {sample_bins} of {F} frequency bins '
-                   f'({t_wpe + t_em:.1f} s measured, x{scale:.1f}), STFT/MVDR/iSTFT in full '
-                   f'({t_stft + t_bf:.1f} s); NumPy float64 restatement of the pb_chime5 CPU '
-                   'path (reference numeric libraries unavailable), 1 thread'),
-        'seconds_per_utterance': total,
+        'value': W * utt2.seconds / cfg2, 'unit': 'utterance-seconds/s', 'cores': W,
+        'kind': 'port', 'cpu_model': model, 'physical_cores': physical,
+        'logical_cpus': logical, 'cgroup_cpu_quota': quota,
+        'per_core_value': utt2.seconds / cfg2,
+        'seconds_per_utterance_per_core': cfg2,
+        'config1': {'per_core_value': utt1.seconds / cfg1, 'aggregate_value': W * utt1.seconds / cfg1,
+                    'seconds_per_utterance_per_core': cfg1,
+                    'sample': 'BASELINE configs[0] (4 ch, 5 s, WPE off, 5 EM iterations), 2 whole '
+                              'utterances per worker, nothing sampled'},
+        'wall_s': wall,
+        'sample': (f'{W} worker processes (usable physical cores - 1, like `mpiexec -np W+1`), each 1 '
+                   f'thread, all running at the same time; per worker one config-2 utterance: '
+                   f'STFT / masks / MVDR+BAN / iSTFT in full '
+                   f'({np.mean([r["cfg2_full_part_s"] for r in res]):.1f} s), WPE + 20 EM '
+                   f'iterations on {sample_bins} of 513 frequency bins '
+                   f'({np.mean([r["cfg2_bins_part_s"] for r in res]):.1f} s, x{513 / sample_bins:.1f}); '
+                   'NumPy float64 restatement of the pb_chime5 CPU path (reference numeric '
+                   'libraries unavailable)'),
     }
 
 
-PROFILE_STEPS = 3
+# ----------------------------------------------------------------------------------
+# workloads
+# ----------------------------------------------------------------------------------
+def to_pcm16(obs):
+    return np.clip(np.rint(obs / np.abs(obs).max() * 30000), -32768, 32767).astype(np.int16)
+
+
+class Config3Pool:
+    """BASELINE configs[2]: 512 dev-shaped utterances (24 ch, K = 5, core length
+    ~ LogNormal(ln 2.5 s, 0.7) clipped to [0.5 s, 15 s] drawn with the seeds of
+    synthetic.config3_item, 240000 context samples on each side).  Generating 512
+    distinct 24-channel recordings costs minutes of host time, so the samples come from
+    a pool of `pool` seeded base recordings with a 15 s core; item i is base i % pool
+    with its core cut to item i's length (context | first U_i of the core | context).
+    Every item is uploaded and enhanced in full; nothing is cached between items."""
+
+    def __init__(self, items, pool, num_channels=24, context=240000):
+        from pb_chime5_amd import synthetic
+        self.context = context
+        self.core_max = 15 * SR
+        self.cores = []
+        for i in range(items):
+            rng = np.random.default_rng(1000 + i + 104729)
+            self.cores.append(int(np.clip(rng.lognormal(np.log(2.5), 0.7), 0.5, 15.0) * SR))
+        self.num_samples = [c + 2 * context for c in self.cores]
+        n = self.core_max + 2 * context
+        self.bases = []
+        for p in range(pool):
+            rng = np.random.default_rng(77 + p)
+            iv = [(context, context + self.core_max)]
+            for _ in range(3):
+                length = int(rng.uniform(0.3, 0.6) * n)
+                a = int(rng.integers(0, n - length))
+                iv.append((a, a + length))
+            u = synthetic.make_utterance(5000 + p, num_channels, n, iv, target=0,
+                                         start_context=context, end_context=context,
+                                         rir_taps=1024, noise=3e-2, fast=True)
+            self.bases.append((to_pcm16(u.obs), u.activity_array.astype(np.uint8)))
+
+    def item(self, i):
+        pcm, act = self.bases[i % len(self.bases)]
+        c, ctx = self.cores[i], self.context
+        a, b = ctx + c, ctx + self.core_max
+        obs = np.concatenate([pcm[:, :a], pcm[:, b:]], axis=1)
+        activity = np.concatenate([act[:, :a], act[:, b:]], axis=1)
+        return obs, activity, 0, ctx, ctx
+
+    def seconds(self, i):
+        return self.num_samples[i] / SR
+
+
+def run_session(pipe, indices, get_item):
+    """What Enhancer._enhance_and_write does per GPU: keep the pipeline full, pop the
+    oldest result when it is.  Returns the number of utterances handled."""
+    count = 0
+    for i in indices:
+        prepared = get_item(i)
+        if pipe.full():
+            pipe.pop()
+        pipe.enqueue(i, *prepared)
+        count += 1
+    while len(pipe):
+        pipe.pop()
+    return count
+
+
+def time_resident(ctx, ops, utt, params, steps, warmup=1):
+    """ms per utterance, one stream, inputs resident in HBM."""
+    ops._prepare_windows(ctx, params.stft_size, params.stft_shift)
+    res = ops.ResidentUtterance(ctx, utt.obs, utt.activity_array, params)
+    c0, c1 = utt.ex['start_orig']['original'], utt.ex['end']['original'] - utt.ex['end_orig']['original']
+    for _ in range(warmup):
+        res.enqueue(utt.target_index, c0, c1)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res.enqueue(utt.target_index, c0, c1)
+    ctx.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    x = res.result()
+    assert np.all(np.isfinite(x)) and x.shape[0] == res.n_out
+    return ms, res
+
+
+def profile_kernels(ctx, res, utt, steps):
+    c0, c1 = utt.ex['start_orig']['original'], utt.ex['end']['original'] - utt.ex['end_orig']['original']
+    ctx.profile_filter(None)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for _ in range(steps):
+        res.enqueue(utt.target_index, c0, c1)
+    ctx.synchronize()
+    prof = ctx.profile_report()
+    ctx.profile_enable(False)
+    return prof
+
+
+def em_loop_entry(prof, steps, iterations, F, T, D, K, roofline):
+    """EM loop (E-step, M-step, model update) per iteration against both roofs
+    (bytes = one pass over the STFT tensor, B_Y = 16 F T D in c128)."""
+    names = [n for n in ('em_estep', 'em_mstep', 'em_chol', 'em_eigh') if n in prof]
+    ms_iter = sum(prof[n]['ms'] for n in names) / steps / iterations
+    by = roofline.stft_bin_bytes(F, T, D)
+    size = dict(F=F, T=T, D=D, K=K, taps=1, N=0)
+    flops = sum(roofline.kernel_work(n, **size)['flops'] for n in ('em_estep', 'em_mstep', 'em_chol'))
+    sec = ms_iter * 1e-3
+    return {
+        'channels': D, 'frames': T, 'classes': K, 'ms_per_iteration': ms_iter,
+        'kernel_ms_per_iteration': {n: prof[n]['ms'] / steps / iterations for n in names},
+        'algorithmic_bytes_per_iteration': by,
+        'hbm_frac': by / sec / 1e9 / roofline.PEAK_HBM_GBS,
+        'executed_flops_per_iteration': flops,
+        'valu_f64_frac': flops / sec / 1e12 / roofline.PEAK_F64_TFLOPS,
+        'binding_roof': 'valu_f64' if flops / roofline.PEAK_F64_TFLOPS / 1e12 >
+        by / roofline.PEAK_HBM_GBS / 1e9 else 'hbm',
+    }
+
+
+# ----------------------------------------------------------------------------------
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=None,
+                    help='config 2: timed steps per rank (default 20); config 3: items (default 512)')
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', type=int, default=2, choices=(2, 3))
+    ap.add_argument('--items', type=int, default=512,
+                    help='config-3 items in the config3_sharded block of a --config 2 run')
+    ap.add_argument('--pool', type=int, default=2, help='config-3 base recordings')
+    ap.add_argument('--inflight', type=int, default=2)
+    ap.add_argument('--static', action='store_true', help='config 3: static instead of dynamic sharding')
+    ap.add_argument('--only-headline', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-bins', type=int, default=24)
+    ap.add_argument('--cpu-workers', type=int, default=None)
+    return ap.parse_args()
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-bins', type=int, default=96)
-    ap.add_argument('--overlap-info', action='store_true',
-                    help='also measure two utterances in flight with PCIe transfers (session mode; '
-                         'informational, off by default so that a rocprofv3 --stats run of the '
-                         'default command sees only back-to-back launches)')
-    args = ap.parse_args()
+    args = parse_args()
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world == 1 and args.gpus > 1:
+        # plain `python bench.py --gpus N`: be our own mpiexec
+        from pb_chime5_amd import parallel
+        sys.exit(parallel.launch_local(args.gpus, [sys.executable, str(Path(__file__).resolve())]
+                                       + sys.argv[1:]))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    # stdout carries exactly ONE line, the result: anything a library prints there (gloo's
+    # connection banner, ...) is sent to stderr, the JSON goes to the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(result_fd, (json.dumps(line) + '\n').encode())
 
     import torch
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run for --gpus > 1')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an AMD GPU (there is no CPU fallback for the hot path)')
-    # GSS_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised on a box with
-    # fewer GPUs than ranks (ranks then share devices); the driver's runs use RCCL.
-    backend = os.environ.get('GSS_BENCH_BACKEND', 'nccl')
-    device_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(device_index)
-    coll_device = 'cuda' if backend == 'nccl' else 'cpu'
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend=backend)
-
-    from pb_chime5_amd import ops, roofline, synthetic
+    from pb_chime5_amd import ops, parallel, roofline, synthetic
+    from pb_chime5_amd import _capi
     from pb_chime5_amd._capi import Context
 
+    rank, local_rank = parallel.rank(), parallel.local_rank()
+    n_dev = torch.cuda.device_count()
+    shared_devices = n_dev < int(os.environ.get('LOCAL_WORLD_SIZE', world))
+    device_index = local_rank % n_dev
+    torch.cuda.set_device(device_index)
+    dist = None
+    coll_device = 'cpu'
+    if world > 1:
+        # RCCL when every rank has its own GPU (the contract's launch), gloo when ranks
+        # share devices; either way it only carries barriers and two scalars.
+        backend = os.environ.get('GSS_BENCH_BACKEND', 'gloo' if shared_devices else 'nccl')
+        dist = parallel.init(backend=backend)
+        coll_device = 'cuda' if backend == 'nccl' else 'cpu'
+
     ctx = Context(device_index)
-    params = ops.make_params(wpe=True, wpe_taps=WORKLOAD['wpe_taps'],
-                             wpe_delay=WORKLOAD['wpe_delay'],
-                             wpe_iterations=WORKLOAD['wpe_iterations'],
-                             bss_iterations=WORKLOAD['bss_iterations'],
-                             bss_iterations_post=WORKLOAD['bss_iterations_post'])
-    ops._prepare_windows(ctx, params.stft_size, params.stft_shift)
-    utt = synthetic.config2(seed=2 + rank, num_channels=WORKLOAD['num_channels'],
-                            seconds=WORKLOAD['seconds'],
-                            num_speakers=WORKLOAD['num_speakers'])
-    ctx_samples = utt.ex['start_orig']['original']
-    resident = ops.ResidentUtterance(ctx, utt.obs, utt.activity_array, params)
+    _capi._DEFAULT_CTX[device_index] = ctx
 
     def barrier():
         ctx.synchronize()
@@ -151,6 +422,105 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(x):
+        if dist is None:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    params = ops.make_params(wpe=True, wpe_taps=WORKLOAD['wpe_taps'],
+                             wpe_delay=WORKLOAD['wpe_delay'],
+                             wpe_iterations=WORKLOAD['wpe_iterations'],
+                             bss_iterations=WORKLOAD['bss_iterations'],
+                             bss_iterations_post=WORKLOAD['bss_iterations_post'])
+    ops._prepare_windows(ctx, params.stft_size, params.stft_shift)
+    F = params.stft_size // 2 + 1
+
+    # ------------------------------------------------------------------ config 3 session
+    def config3_session(items):
+        """All ranks pull the items of BASELINE configs[2] from the shared longest-first
+        queue (parallel.split_managed), `inflight` utterances in flight per GPU, PCM16
+        H2D and float64 D2H inside the wall clock."""
+        t_gen = time.perf_counter()
+        pool = Config3Pool(items, args.pool)
+        t_gen = time.perf_counter() - t_gen
+        pipe = ops.UtterancePipeline(params, depth=args.inflight, first_ctx=ctx)
+        longest = int(np.argmax(pool.num_samples))
+        run_session(pipe, [longest] * (args.inflight + 1), pool.item)     # warm-up: arenas sized
+        barrier()
+        t0 = time.perf_counter()
+        mine = parallel.split_managed(range(items), costs=pool.num_samples,
+                                      dynamic=not args.static)
+        handled = []
+
+        def get(i):
+            handled.append(i)
+            return pool.item(i)
+        run_session(pipe, mine, get)
+        local = time.perf_counter() - t0
+        barrier()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        secs = sum_over_ranks(sum(pool.seconds(i) for i in handled))
+        total = sum_over_ranks(len(handled))
+        busiest = max_over_ranks(len(handled))
+        slowest_local = max_over_ranks(local)
+        pipe.close()
+        assert int(total) == items, (total, items)
+        return {
+            'workload': (f'BASELINE.json configs[2]: {items} dev-shaped utterances (24 ch, K = 5, '
+                         'core 0.5-15 s + 2 x 15 s context, T = 1906-2815), samples from '
+                         f'{args.pool} seeded base recordings cut to each item\'s length; WPE '
+                         'taps=10, 20 EM iterations, MVDR+BAN'),
+            'sharding': ('static longest-first round-robin' if args.static else
+                         'dynamic: shared counter in the launcher\'s TCP store, longest first '
+                         '(parallel.split_managed)') if world > 1 else 'single rank',
+            'items': items, 'utterances_in_flight_per_gpu': args.inflight,
+            'includes': 'H2D (PCM16) + D2H per utterance, host-side slicing of the item',
+            'utterance_seconds': secs, 'wall_s': wall,
+            'value': secs / wall, 'unit': 'utterance-seconds/s',
+            'ms_per_utterance': 1e3 * wall / items * world,
+            'items_on_busiest_rank': int(busiest), 'slowest_rank_busy_s': slowest_local,
+            'host_generation_s': t_gen,
+        }
+
+    if args.config == 3:
+        items = args.steps or 512
+        block = config3_session(items)
+        if rank == 0:
+            line = {
+                'metric': 'utterance-seconds enhanced/sec (24ch, 20 EM iters), sharded session',
+                'value': block['value'], 'unit': 'utterance-seconds/s', 'n_gpus': args.gpus,
+                'steps': items, 'warmup': args.inflight + 1,
+                'ms_per_step': 1e3 * block['wall_s'] / items,
+                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+                'dtype': 'f64', 'data': 'synthetic',
+                'config': {'workload': block['workload'], 'sharding': block['sharding'],
+                           'parallelism': f'utterance-sharded x{args.gpus}'
+                                          + (' (ranks share GPUs)' if shared_devices else '')},
+                'config3_sharded': block,
+            }
+            emit(line)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ------------------------------------------------------------------ config 2 headline
+    steps = args.steps or 20
+    utt = synthetic.config2(seed=2 + rank, num_channels=WORKLOAD['num_channels'],
+                            seconds=WORKLOAD['seconds'],
+                            num_speakers=WORKLOAD['num_speakers'])
+    ctx_samples = utt.ex['start_orig']['original']
+    resident = ops.ResidentUtterance(ctx, utt.obs, utt.activity_array, params)
 
     def step():
         resident.enqueue(utt.target_index, ctx_samples, ctx_samples)
@@ -162,13 +532,7 @@ def main():
     # name of the dominant kernel.  (Two events per launch cost ~4 us of stream time
     # each; around all ~260 launches of an utterance that is 6 % of the step, so the
     # timed region below only carries events around the dominant kernel.)
-    ctx.profile_filter(None)
-    ctx.profile_enable(True)
-    ctx.profile_reset()
-    for _ in range(PROFILE_STEPS):
-        step()
-    ctx.synchronize()
-    prof_all = ctx.profile_report()
+    prof_all = profile_kernels(ctx, resident, utt, PROFILE_STEPS)
     dominant = max(prof_all, key=lambda k: prof_all[k]['ms'])
     if dist is not None:       # every rank times the same kernel
         names = sorted(prof_all)
@@ -176,10 +540,11 @@ def main():
         dist.broadcast(idx, src=0)
         dominant = names[int(idx.item())]
     ctx.profile_filter(dominant)
+    ctx.profile_enable(True)
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     ctx.synchronize()
     torch.cuda.synchronize()
@@ -190,43 +555,85 @@ def main():
     ctx.profile_filter(None)
     x_hat = resident.result()
     assert np.all(np.isfinite(x_hat)) and x_hat.shape[0] == resident.n_out
+    elapsed = max_over_ranks(elapsed)
 
-    # Informational only (not part of `value`): the session driver's mode -- two
-    # utterances in flight on two contexts / HIP streams (ops.UtterancePipeline), which
-    # lets one utterance's latency-bound kernels overlap the other's compute-bound
-    # ones.  This figure INCLUDES the H2D copy of every utterance's samples and the D2H
-    # copy of the result; like the session driver it uploads the samples as 16-bit PCM
-    # (the STFT kernel converts them).
-    overlap = None
-    if args.overlap_info and rank == 0:
-        pipe = ops.UtterancePipeline(params, depth=2, first_ctx=ctx)
-        n2 = max(args.steps, 4)
-        pcm = np.clip(np.rint(utt.obs / np.abs(utt.obs).max() * 30000), -32768, 32767).astype(np.int16)
-
-        def run(count):
-            for i in range(count):
-                if pipe.full():
-                    pipe.pop()
-                pipe.enqueue(i, pcm, utt.activity_array, utt.target_index, ctx_samples,
-                             ctx_samples)
-            while len(pipe):
-                pipe.pop()
-        run(2)
+    extras = not args.only_headline
+    # ---- session mode on the same workload: 2 in flight, H2D + D2H inside the wall clock
+    incl = None
+    if extras:
+        pipe = ops.UtterancePipeline(params, depth=args.inflight, first_ctx=ctx)
+        pcm = to_pcm16(utt.obs)
+        item = (pcm, utt.activity_array, utt.target_index, ctx_samples, ctx_samples)
+        n2 = max(steps, 8)
+        run_session(pipe, range(args.inflight + 1), lambda i: item)
+        barrier()
         t2 = time.perf_counter()
-        run(n2)
+        run_session(pipe, range(n2), lambda i: item)
         e2 = time.perf_counter() - t2
-        overlap = {'utterances_in_flight': 2, 'utterances': n2, 'includes': 'H2D (PCM16) + D2H per utterance',
-                   'value': n2 * utt.seconds / e2, 'unit': 'utterance-seconds/s'}
+        barrier()
+        e2 = max_over_ranks(e2)
         pipe.close()
+        incl = {'value': args.gpus * n2 * utt.seconds / e2, 'unit': 'utterance-seconds/s',
+                'utterances_per_rank': n2, 'utterances_in_flight_per_gpu': args.inflight,
+                'ms_per_utterance': 1e3 * e2 / n2,
+                'includes': 'H2D of the 24 x 240000 PCM16 samples + activity and D2H of the float64 '
+                            'result for every utterance (pageable host memory)'}
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ---- the other BASELINE configs, in-process (rank 0 of a single-GPU run only)
+    configs = None
+    em_loop = None
+    if extras and rank == 0 and args.gpus == 1:
+        configs = {}
+        size2 = dict(F=F, T=resident.T, D=resident.D, K=resident.K)
+        em_loop = {'D24': em_loop_entry(prof_all, PROFILE_STEPS, WORKLOAD['bss_iterations'],
+                                        roofline=roofline, **size2)}
+
+        def timed(name, u, p, nsteps, note):
+            ms, res = time_resident(ctx, ops, u, p, nsteps)
+            configs[name] = {'ms_per_utterance': ms, 'utterance_seconds': u.seconds,
+                             'value': 1e3 * u.seconds / ms, 'unit': 'utterance-seconds/s',
+                             'channels': res.D, 'frames': res.T, 'classes': res.K,
+                             'workload': note, 'mode': 'one stream, inputs resident in HBM'}
+            return res
+        timed('1', synthetic.config1(),
+              ops.make_params(wpe=False, bss_iterations=5, bss_iterations_post=1), 10,
+              'configs[0]: 4 mics, 5 s, 2 speakers + Noise, WPE off, 5 EM iterations, MVDR+BAN')
+        configs['2'] = {'ms_per_utterance': 1e3 * elapsed / steps, 'utterance_seconds': utt.seconds,
+                        'value': steps * utt.seconds / elapsed, 'unit': 'utterance-seconds/s',
+                        'channels': resident.D, 'frames': resident.T, 'classes': resident.K,
+                        'workload': 'configs[1] (the headline)', 'mode': 'one stream, inputs resident in HBM'}
+        sr = SR
+        n3 = 554490                          # synthetic.config3_item(0): 4.66 s core + 2 x 15 s
+        iv3 = [(240000, n3 - 240000), (100000, 400000), (50000, 250000), (300000, 520000)]
+        u3 = synthetic.make_utterance(1000, 24, n3, iv3, start_context=240000, end_context=240000,
+                                      rir_taps=1024, noise=3e-2, fast=True)
+        timed('3-item', u3, params, 5,
+              'one dev-shaped item of configs[2]: 24 ch, 34.7 s incl. 2 x 15 s context, as config 2')
+        u1a = synthetic.make_utterance(1001, 4, n3, iv3, start_context=240000, end_context=240000,
+                                       rir_taps=1024, noise=3e-2, fast=True)
+        res4 = timed('3-item-one-array', u1a, params, 5,
+                     'the reference default multiarray=False: one array (4 ch) of the same item')
+        prof4 = profile_kernels(ctx, res4, u1a, PROFILE_STEPS)
+        em_loop['D4'] = em_loop_entry(prof4, PROFILE_STEPS, WORKLOAD['bss_iterations'],
+                                      F=F, T=res4.T, D=res4.D, K=res4.K, roofline=roofline)
+        n5 = 120 * sr
+        iv5 = [(50 * sr, 70 * sr), (10 * sr, 60 * sr), (40 * sr, 100 * sr), (65 * sr, 115 * sr)]
+        u5 = synthetic.make_utterance(5, 12, n5, iv5, start_context=50 * sr, end_context=50 * sr,
+                                      fast=True)
+        timed('5', u5, ops.make_params(wpe=True, wpe_taps=10, wpe_delay=2, wpe_iterations=3,
+                                       bss_iterations=40, bss_iterations_post=1, bf='gev_ban'), 3,
+              'configs[4]: 120 s segment, 12 ch (outer_array_mics), WPE, 40 EM iterations, GEV + BAN')
+        configs['4'] = {'status': 'not run: corpus unavailable',
+                        'workload': 'configs[3]: CHiME-5 dev session S02 (needs the CHiME-5 audio and '
+                                    'cache/chime5.json; `python -m pb_chime5_amd.scripts.run with '
+                                    'session_id=S02 multiarray=True` is the harness hook)'}
+
+    # ---- BASELINE configs[2] through the shared queue (all ranks)
+    sharded = config3_session(args.items) if extras else None
 
     if rank == 0:
-        size = dict(F=params.stft_size // 2 + 1, T=resident.T, D=resident.D, K=resident.K,
-                    taps=WORKLOAD['wpe_taps'], N=resident.N)
+        size = dict(F=F, T=resident.T, D=resident.D, K=resident.K, taps=WORKLOAD['wpe_taps'],
+                    N=resident.N)
         total_ms = sum(v['ms'] for v in prof_all.values())
         kernels = {}
         for name, v in sorted(prof_all.items(), key=lambda kv: -kv[1]['ms']):
@@ -249,10 +656,10 @@ def main():
                 pass
         line = {
             'metric': 'utterance-seconds enhanced/sec/GPU (24ch, 20 EM iters)',
-            'value': args.gpus * args.steps * utt.seconds / elapsed,
+            'value': args.gpus * steps * utt.seconds / elapsed,
             'unit': 'utterance-seconds/s',
-            'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps,
+            'n_gpus': args.gpus, 'steps': steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {
@@ -261,22 +668,29 @@ def main():
                              '20 EM iterations + predict, MVDR-Souden + BAN; inputs resident in HBM'),
                 'utterance_seconds': utt.seconds, 'channels': resident.D,
                 'frames': resident.T, 'classes': resident.K,
-                'utterances_per_step_per_gpu': 1, 'parallelism': f'utterance-sharded x{args.gpus}',
+                'utterances_per_step_per_gpu': 1,
+                'parallelism': f'utterance-sharded x{args.gpus}'
+                               + (' (ranks share GPUs)' if shared_devices else ''),
             },
-            'realtime_factor_per_gpu': args.steps * utt.seconds / elapsed,
+            'realtime_factor_per_gpu': steps * utt.seconds / elapsed,
+            'value_incl_pcie': incl['value'] if incl else None,
+            'session_mode': incl,
             'roofline': roof,
             'kernels': kernels,
             'kernels_note': (f'per-kernel table from an untimed pass of {PROFILE_STEPS} steps with HIP '
                              'events around every launch; `roofline` is the dominant kernel timed '
-                             'inside the timed region'),
+                             'inside the timed region; frac_of_roof prices the minimum flops / bytes '
+                             'of each kernel\'s formulation (pb_chime5_amd/roofline.py)'),
             'device_ms_per_step': total_ms / PROFILE_STEPS,
             'workspace_bytes': ctx.workspace_bytes(),
-            'pipelined_session_info': overlap,
+            'em_loop': em_loop,
+            'configs': configs,
+            'config3_sharded': sharded,
         }
-        if args.gpus == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(utt, args.cpu_bins)
-            line['speedup_vs_cpu_core'] = line['value'] / line['cpu_baseline']['value']
-        print(json.dumps(line))
+        if args.gpus == 1 and extras and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(utt, args.cpu_bins, args.cpu_workers)
+            line['speedup_vs_cpu_all_cores'] = line['value'] / line['cpu_baseline']['value']
+        emit(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -64,6 +64,10 @@ typedef enum {
 #define GSS_MAX_STFT_SIZE 4096
 
 /* ---- context ----------------------------------------------------------- */
+/* Number of visible HIP devices (0 if none / no driver).  Ranks of a node pick
+ * LOCAL_RANK % gss_device_count() (pb_chime5_amd.parallel, replacing dlp_mpi's
+ * rank handling at core.py:363-381). */
+int gss_device_count(void);
 int gss_create(int device_id, gss_ctx **ctx);
 int gss_destroy(gss_ctx *ctx);
 const char *gss_last_error(gss_ctx *ctx);

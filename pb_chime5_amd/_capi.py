@@ -40,6 +40,7 @@ class GssDebugTaps(ctypes.Structure):
 
 # name -> (restype, argtypes); every symbol include/gss_hip.h declares
 SIGNATURES = {
+    'gss_device_count': (c_int, []),
     'gss_create': (c_int, [c_int, ctypes.POINTER(c_void_p)]),
     'gss_destroy': (c_int, [c_void_p]),
     'gss_last_error': (ctypes.c_char_p, [c_void_p]),
@@ -265,10 +266,23 @@ class Context:
 _DEFAULT_CTX = {}
 
 
+def device_count():
+    return int(load_library().gss_device_count())
+
+
+def default_device():
+    """$GSS_DEVICE, else LOCAL_RANK modulo the number of visible GPUs (ranks share
+    devices when a node has fewer GPUs than ranks), else 0."""
+    if 'GSS_DEVICE' in os.environ:
+        return int(os.environ['GSS_DEVICE'])
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    return local_rank % max(device_count(), 1) if local_rank else 0
+
+
 def default_context(device_id=None):
-    """Process-wide context for ``device_id`` (default: $GSS_DEVICE or LOCAL_RANK or 0)."""
+    """Process-wide context for ``device_id`` (default: ``default_device()``)."""
     if device_id is None:
-        device_id = int(os.environ.get('GSS_DEVICE', os.environ.get('LOCAL_RANK', 0)))
+        device_id = default_device()
     ctx = _DEFAULT_CTX.get(device_id)
     if ctx is None or ctx.handle is None:
         ctx = _DEFAULT_CTX[device_id] = Context(device_id)

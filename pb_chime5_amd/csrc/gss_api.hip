@@ -6,6 +6,12 @@
 
 #include "gss_internal.h"
 
+// Every entry point that touches the device makes the context's GPU current first:
+// one process (and thread) may interleave contexts of different GPUs.
+#define GSS_ENTER(ctx)                                   \
+    if (!(ctx)) return GSS_ERR_INVALID;                  \
+    GSS_HIP_CHECK((ctx), hipSetDevice((ctx)->device))
+
 // ------------------------------------------------------------------ errors
 int gss_fail(gss_ctx *ctx, int code, const char *fmt, ...) {
     char buf[1024];
@@ -27,6 +33,12 @@ extern "C" const char *gss_last_error(gss_ctx *ctx) {
 extern "C" const char *gss_version(void) { return "pb_chime5_amd/libgss_hip 0.1 (gfx950, f64)"; }
 
 // ------------------------------------------------------------------ context
+extern "C" int gss_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
 extern "C" int gss_create(int device_id, gss_ctx **out) {
     if (!out) return GSS_ERR_INVALID;
     *out = nullptr;
@@ -85,7 +97,7 @@ extern "C" int gss_destroy(gss_ctx *ctx) {
 }
 
 extern "C" int gss_set_stream(gss_ctx *ctx, void *hip_stream) {
-    if (!ctx) return GSS_ERR_INVALID;
+    GSS_ENTER(ctx);
     GSS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     return GSS_OK;
@@ -121,7 +133,7 @@ extern "C" int gss_dev_free(gss_ctx *ctx, void *dev_ptr) {
 }
 
 extern "C" int gss_memcpy_h2d(gss_ctx *ctx, void *dst, const void *src, size_t bytes) {
-    if (!ctx) return GSS_ERR_INVALID;
+    GSS_ENTER(ctx);
     if (bytes == 0) return GSS_OK;
     GSS_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     // pageable host memory: the copy is staged before the call returns, but be
@@ -131,7 +143,7 @@ extern "C" int gss_memcpy_h2d(gss_ctx *ctx, void *dst, const void *src, size_t b
 }
 
 extern "C" int gss_memcpy_d2h(gss_ctx *ctx, void *dst, const void *src, size_t bytes) {
-    if (!ctx) return GSS_ERR_INVALID;
+    GSS_ENTER(ctx);
     if (bytes == 0) return GSS_OK;
     GSS_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     GSS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -139,7 +151,7 @@ extern "C" int gss_memcpy_d2h(gss_ctx *ctx, void *dst, const void *src, size_t b
 }
 
 extern "C" int gss_memset(gss_ctx *ctx, void *dst, int value, size_t bytes) {
-    if (!ctx) return GSS_ERR_INVALID;
+    GSS_ENTER(ctx);
     if (bytes == 0) return GSS_OK;
     GSS_HIP_CHECK(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
     return GSS_OK;
@@ -316,9 +328,6 @@ extern "C" int gss_set_windows(gss_ctx *ctx, int size, int shift, const double *
 }
 
 // ------------------------------------------------------------------ stage wrappers
-#define GSS_ENTER(ctx)                                   \
-    if (!(ctx)) return GSS_ERR_INVALID;                  \
-    GSS_HIP_CHECK((ctx), hipSetDevice((ctx)->device))
 
 static int check_windows(gss_ctx *ctx) {
     GSS_REQUIRE(ctx, ctx->stft_size > 0, GSS_ERR_INVALID, "call gss_set_windows() first");

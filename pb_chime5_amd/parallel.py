@@ -12,8 +12,15 @@ each pulling utterance indices either
   store is reachable.
 
 Single-process runs degrade to a plain loop (``allow_single_worker=True`` upstream).
+
+``launch_local(n, argv)`` is the stand-in for ``mpiexec -np n`` (reference
+README.md:108-111): it starts n copies of a command on this node, one per GPU, with
+the rendezvous variables torch.distributed.run would set.
 """
 import os
+import socket
+import subprocess
+import sys
 
 _STATE = {'store': None, 'epoch': 0}
 
@@ -30,6 +37,13 @@ def local_rank():
     return int(os.environ.get('LOCAL_RANK', 0))
 
 
+def device_index():
+    """The GPU of this rank: LOCAL_RANK modulo the number of visible GPUs (ranks share
+    devices on a node with fewer GPUs than ranks)."""
+    from pb_chime5_amd import _capi
+    return _capi.default_device()
+
+
 def is_master():
     return rank() == 0
 
@@ -44,17 +58,23 @@ def _dist():
 
 
 def init(backend=None):
-    """Join the process group of the launcher (gloo on CPU-only hosts, nccl = RCCL
-    otherwise).  Only host-side rendezvous, barrier and the work counter use it."""
+    """Join the process group of the launcher.  Only host-side rendezvous, barriers and
+    the work counter use it, so gloo always suffices; nccl (= RCCL) is picked when every
+    local rank has a GPU of its own, gloo on CPU-only hosts and when ranks share GPUs
+    (a node with fewer GPUs than ranks: device = LOCAL_RANK % device count)."""
     if world_size() == 1:
         return None
     import torch
     import torch.distributed as dist
     if not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('GSS_DIST_BACKEND')
+        if backend is None:
+            local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world_size()))
+            n_gpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            backend = 'nccl' if n_gpu >= local_world else 'gloo'
         if backend == 'nccl':
-            torch.cuda.set_device(local_rank())
+            torch.cuda.set_device(device_index())
         dist.init_process_group(backend=backend)
     return dist
 
@@ -112,3 +132,62 @@ def split_managed(sequence, costs=None, dynamic=True):
             break
         yield items[order[pos]]
     barrier()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_local(nprocs, argv, extra_env=None, timeout=None):
+    """Run ``argv`` as ``nprocs`` ranks on this node (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment) and wait for all of
+    them.  Rank 0 inherits this process's stdout; the other ranks' stdout goes to
+    stderr, so a command that prints one result line on rank 0 still prints exactly
+    one.  Returns the first non-zero exit status (the remaining ranks are terminated
+    by PID), else 0."""
+    port = free_port()
+    procs = []
+    for r in range(nprocs):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nprocs),
+                   LOCAL_WORLD_SIZE=str(nprocs), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    import time
+    deadline = None if timeout is None else time.monotonic() + timeout
+    status = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            rc = p.poll()
+            if rc is None:
+                continue
+            pending.remove(p)
+            if rc != 0 and status == 0:
+                status = rc
+        if status != 0 or (deadline is not None and time.monotonic() > deadline):
+            for p in pending:
+                p.terminate()
+            for p in pending:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            return status or 124
+        time.sleep(0.05)
+    return status
+
+
+def _main(argv=None):
+    """``python -m pb_chime5_amd.parallel -n N <python args...>``: the node-local
+    ``mpiexec -np N python <python args...>``."""
+    argv = sys.argv[1:] if argv is None else list(argv)
+    if len(argv) < 3 or argv[0] not in ('-n', '-np'):
+        raise SystemExit('usage: python -m pb_chime5_amd.parallel -n N [-m module | script.py] args...')
+    return launch_local(int(argv[1]), [sys.executable] + argv[2:])
+
+
+if __name__ == '__main__':
+    sys.exit(_main())

@@ -49,7 +49,7 @@ def main(argv=None):
         wpe_delay=args.wpe_delay, wpe_iterations=args.wpe_iterations,
         bss_iterations=args.bss_iterations, bss_iterations_post=args.bss_iterations_post,
         bf_drop_context=not args.no_bf_drop_context, bf=args.bf, postfilter=args.postfilter,
-        device_id=parallel.local_rank())
+        device_id=parallel.device_index())
     if parallel.is_master():
         Path(args.out).mkdir(parents=True, exist_ok=True)
     parallel.barrier()

@@ -29,7 +29,7 @@ def run(get_enhancer, config, test_run, script_keys=SCRIPT_KEYS):
     if parallel.is_master():
         _cli.new_run_dir(Path(storage_dir) / 'sacred', config)
     kwargs = {k: v for k, v in config.items() if k not in script_keys}
-    enhancer = get_enhancer(**kwargs, device_id=parallel.local_rank())
+    enhancer = get_enhancer(**kwargs, device_id=parallel.device_index())
     if test_run:
         print('Database', enhancer.db)
         dataset_slice = True

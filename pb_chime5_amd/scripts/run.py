@@ -64,7 +64,7 @@ def main(argv=None):
     run_dir = _cli.broadcast_path(run_dir)
 
     kwargs = {k: v for k, v in config.items() if k not in ('chime6', 'session_id')}
-    enhancer = get_enhancer(**kwargs, device_id=parallel.local_rank())
+    enhancer = get_enhancer(**kwargs, device_id=parallel.device_index())
     if test_run:
         print('Database', enhancer.db)
     session_ids = get_session_ids(config['session_id'])

@@ -52,24 +52,57 @@ def _rir(rng, taps=2048):
     return h
 
 
+def _reverberate_fast(src, rirs, num_samples):
+    """Sum over sources of src[k] * rirs[k, d] for all microphones with one batched FFT
+    (the sum is taken in the frequency domain: K + K*D + D transforms instead of K*D
+    full convolutions).  Same signal as the per-pair ``fftconvolve`` loop up to
+    rounding (~1e-16 relative), ~20x faster; used where the bytes need not equal the
+    slow path's (bench workloads)."""
+    import scipy.fft as sfft
+    K, D, taps = rirs.shape
+    nfft = sfft.next_fast_len(num_samples + taps - 1, real=True)
+    S = sfft.rfft(src, nfft, axis=-1, workers=-1)                    # (K, nf)
+    out = np.zeros((D, nfft // 2 + 1), dtype=np.complex128)
+    for k in range(K):
+        out += S[k] * sfft.rfft(rirs[k], nfft, axis=-1, workers=-1)
+    return sfft.irfft(out, nfft, axis=-1, workers=-1)[:, :num_samples]
+
+
 def make_utterance(seed, num_channels, num_samples, intervals, target=0,
-                   start_context=0, end_context=0, rir_taps=2048, noise=1e-3):
+                   start_context=0, end_context=0, rir_taps=2048, noise=1e-3, fast=False,
+                   diffuse_noise=0.0):
     """intervals: list of (start, stop) sample pairs, one per speaker; the
     ``Noise`` class is appended as all-True.  ``start_context``/``end_context``
-    are the context samples on each side of the core segment."""
+    are the context samples on each side of the core segment.
+
+    ``diffuse_noise`` > 0 adds a spatially diffuse background (an independent coloured
+    noise of that RMS, relative to one speech source, at every microphone), which keeps
+    the distortion PSD matrix well conditioned in every frequency bin; the SURVEY 8d
+    generator (``diffuse_noise=0``, white sensor noise only) leaves it nearly singular
+    wherever a few frames carry the whole distortion mask."""
     from scipy.signal import fftconvolve
     rng = np.random.default_rng(seed)
     obs = np.zeros((num_channels, num_samples))
     activity = {}
+    srcs, rirs = [], []
     for k, (a, b) in enumerate(intervals):
         act = np.zeros(num_samples, dtype=bool)
         act[a:b] = True
         activity[f'P{k + 1:02d}'] = act
         src = _source(rng, num_samples) * act
+        if fast:
+            srcs.append(src)
+            rirs.append(np.stack([_rir(rng, rir_taps) for _ in range(num_channels)]))
+            continue
         for d in range(num_channels):
             obs[d] += fftconvolve(src, _rir(rng, rir_taps))[:num_samples]
+    if fast and srcs:
+        obs += _reverberate_fast(np.stack(srcs), np.stack(rirs), num_samples)
     activity['Noise'] = np.ones(num_samples, dtype=bool)
     obs += rng.standard_normal(obs.shape) * noise
+    if diffuse_noise > 0:
+        for d in range(num_channels):
+            obs[d] += _source(rng, num_samples) * diffuse_noise
     obs *= 0.1
     speaker_id = f'P{target + 1:02d}'
     ex = {
