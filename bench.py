@@ -607,8 +607,13 @@ def main():
         iv3 = [(240000, n3 - 240000), (100000, 400000), (50000, 250000), (300000, 520000)]
         u3 = synthetic.make_utterance(1000, 24, n3, iv3, start_context=240000, end_context=240000,
                                       rir_taps=1024, noise=3e-2, fast=True)
-        timed('3-item', u3, params, 5,
-              'one dev-shaped item of configs[2]: 24 ch, 34.7 s incl. 2 x 15 s context, as config 2')
+        res3 = timed('3-item', u3, params, 5,
+                     'one dev-shaped item of configs[2]: 24 ch, 34.7 s incl. 2 x 15 s context, as config 2')
+        prof3 = profile_kernels(ctx, res3, u3, PROFILE_STEPS)
+        em_loop['D24_T2169'] = em_loop_entry(prof3, PROFILE_STEPS, WORKLOAD['bss_iterations'],
+                                             F=F, T=res3.T, D=res3.D, K=res3.K, roofline=roofline)
+        configs['3-item']['kernel_ms_per_utterance'] = {
+            k: round(v['ms'] / PROFILE_STEPS, 4) for k, v in sorted(prof3.items(), key=lambda kv: -kv[1]['ms'])}
         u1a = synthetic.make_utterance(1001, 4, n3, iv3, start_context=240000, end_context=240000,
                                        rir_taps=1024, noise=3e-2, fast=True)
         res4 = timed('3-item-one-array', u1a, params, 5,

@@ -125,10 +125,12 @@ int gss_istft(gss_ctx *ctx, const gss_cplx *X_dev, int64_t T, int fading,
 int gss_activity_time_to_frequency(gss_ctx *ctx, const uint8_t *act_dev, int K,
                                    int64_t N, int fading, uint8_t *act_frames_dev);
 
-/* A2  WPE.__call__ -> nara_wpe.wpe.wpe_v8(statistics_mode='full',
- * psd_context=0) (core.py:48-58).  Y (F,T,D) -> X (F,T,D); X may equal Y. */
+/* A2  WPE.__call__ -> nara_wpe.wpe.wpe_v8(statistics_mode='full') (core.py:48-58).
+ * psd_context (core.py:56,583; nara_wpe.wpe.get_power): the frame power is averaged
+ * over the existing frames of [t - psd_context, t + psd_context]; 0 = the reference
+ * default.  Y (F,T,D) -> X (F,T,D); X must not alias Y unless iterations == 0. */
 int gss_wpe(gss_ctx *ctx, const gss_cplx *Y_dev, int F, int64_t T, int D,
-            int taps, int delay, int iterations, gss_cplx *X_dev);
+            int taps, int delay, int iterations, int psd_context, gss_cplx *X_dev);
 
 /* A4-A6  GSS.__call__ (core.py:154-214): initialisation from the frame activity,
  * CACGMMTrainer.fit(iterations, source_activity_mask) and the post step
@@ -157,6 +159,20 @@ int gss_mvdr_souden(gss_ctx *ctx, const gss_cplx *Y_dev, int F, int64_t T, int D
                     const double *target_mask_dev,
                     const double *distortion_mask_dev, int ban,
                     gss_cplx *Xhat_dev, int32_t *ref_channel_dev);
+
+/* The same with the reference channel named by the caller (pb_bss
+ * get_mvdr_vector_souden(ref_channel=...), call site beamforming_wrapper.py:58-63). */
+int gss_mvdr_souden_ref(gss_ctx *ctx, const gss_cplx *Y_dev, int F, int64_t T, int D,
+                        const double *target_mask_dev,
+                        const double *distortion_mask_dev, int ban, int ref_channel,
+                        gss_cplx *Xhat_dev);
+
+/* Reference channel of the last MVDR run on this context (gss_mvdr_souden or the fused
+ * pipeline); synchronises the stream.  -1: a per-channel SNR was not finite -- pb_bss
+ * get_optimal_reference_channel asserts np.all(np.isfinite(SNR)) and the reference
+ * aborts the utterance with an AssertionError; here Xhat is filled with NaN and the host
+ * raises.  INT32_MIN: no MVDR has run yet. */
+int gss_last_ref_channel(gss_ctx *ctx, int32_t *ref_channel_host);
 
 /* beamform_gev_from_masks (beamforming_wrapper.py:77-89,192-208): masked PSD
  * matrices, principal generalised eigenvector of (Phi_X, Phi_N) with
@@ -193,6 +209,7 @@ typedef struct {
     int bf;                   /* 0 = 'mvdrSouden_ban', 1 = 'ch2', 2 = 'sum',   */
                               /* 3 = 'gev_ban' (not in the reference's dispatch) */
     int postfilter;           /* 0 = None, 1 = 'mask_mul'                      */
+    int wpe_psd_context;      /* 0: frames either side averaged into the WPE power */
 } gss_params;
 
 /* Optional taps into the pipeline's intermediates (device pointers; any may be

@@ -228,11 +228,24 @@ def build_y_tilde(Y, taps, delay):
     return out.reshape(taps * D, T)
 
 
-def get_power_inverse(signal, psd_context=0):
-    """1 / max(mean_d |X|^2, 1e-10 * max_t power); only psd_context == 0 is on
-    the reference path (core.py:583)."""
-    assert psd_context == 0, psd_context
+def get_power(signal, psd_context=0):
+    """nara_wpe.wpe.get_power: mean_d |X|^2 per frame; psd_context = p > 0 (an int;
+    core.py:583 exposes it as wpe_psd_context, default 0) averages it over the frames
+    t-p..t+p that exist: np.correlate with ones(2p + 1) in 'full' mode, cropped to the T
+    centred lags and divided by the same correlation of an all-ones signal."""
     power = np.mean(signal.real ** 2 + signal.imag ** 2, axis=-2)
+    if psd_context != 0:
+        assert int(psd_context) == psd_context and psd_context > 0, psd_context
+        p = int(psd_context)
+        kernel = np.ones(2 * p + 1)
+        power = np.correlate(power, kernel, mode='full')[p:-p]
+        power = power / np.correlate(np.ones_like(power), kernel, mode='full')[p:-p]
+    return power
+
+
+def get_power_inverse(signal, psd_context=0):
+    """1 / max(power, 1e-10 * max_t power)."""
+    power = get_power(signal, psd_context)
     eps = 1e-10 * np.max(power)
     return 1 / np.maximum(power, eps)
 
@@ -538,16 +551,18 @@ def beamform_mvdr_souden_from_masks(Y, X_mask, N_mask, ban=False,
 # --------------------------------------------------------------------------
 def enhance_observation(obs, activity, target_index, ex=None, *,
                         wpe=True, wpe_taps=10, wpe_delay=2, wpe_iterations=3,
+                        wpe_psd_context=0,
                         stft_size=1024, stft_shift=256, stft_fading=True,
                         bss_iterations=20, bss_iterations_post=1,
                         bf_drop_context=True, bf='mvdrSouden_ban',
                         postfilter=None, return_details=False,
-                        gss_fn=None):
+                        gss_fn=None, wpe_fn=None):
     """obs (D,N) float64; activity (K,N) bool in dict order; target_index = the
     row of the target speaker.  Returns x_hat (N',) float64."""
     Obs = stft(obs, stft_size, stft_shift, fading=stft_fading)
     if wpe:
-        Obs = wpe_block(Obs, wpe_taps, wpe_delay, wpe_iterations)
+        Obs = (wpe_block if wpe_fn is None else wpe_fn)(
+            Obs, wpe_taps, wpe_delay, wpe_iterations, wpe_psd_context)
     activity_freq = activity_time_to_frequency(
         np.asarray(activity), stft_size, stft_shift, stft_fading, stft_pad=True)
     gss = gss_block if gss_fn is None else gss_fn

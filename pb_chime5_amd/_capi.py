@@ -29,7 +29,7 @@ class GssParams(ctypes.Structure):
     _fields_ = [(n, c_int) for n in (
         'stft_size', 'stft_shift', 'stft_fading', 'wpe', 'wpe_taps', 'wpe_delay',
         'wpe_iterations', 'bss_iterations', 'bss_iterations_post',
-        'bf_drop_context', 'bf', 'postfilter')]
+        'bf_drop_context', 'bf', 'postfilter', 'wpe_psd_context')]
 
 
 class GssDebugTaps(ctypes.Structure):
@@ -65,7 +65,7 @@ SIGNATURES = {
     'gss_activity_time_to_frequency': (
         c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     'gss_wpe': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int,
-                        c_int, c_void_p]),
+                        c_int, c_int, c_void_p]),
     'gss_cacgmm': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p,
                            c_int, c_int, c_int, c_void_p]),
     'gss_masks_from_posteriors': (
@@ -73,6 +73,9 @@ SIGNATURES = {
                 c_int64, c_void_p, c_void_p]),
     'gss_mvdr_souden': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int,
                                 c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'gss_mvdr_souden_ref': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int,
+                                    c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'gss_last_ref_channel': (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int32)]),
     'gss_gev': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int,
                         c_void_p]),
     'gss_layout_dtf_to_ftd': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int,
@@ -245,6 +248,13 @@ class Context:
         self._check(self.lib.gss_profile_report(self.handle, buf, len(buf)),
                     'profile_report')
         return json.loads(buf.value.decode())
+
+    def last_ref_channel(self):
+        """Reference channel of the last MVDR run (synchronises); -1 = non-finite SNR."""
+        out = ctypes.c_int32()
+        self._check(self.lib.gss_last_ref_channel(self.handle, ctypes.byref(out)),
+                    'gss_last_ref_channel')
+        return int(out.value)
 
     def workspace_bytes(self):
         return int(self.lib.gss_workspace_bytes(self.handle))

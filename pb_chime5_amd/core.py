@@ -436,7 +436,6 @@ class Enhancer:
         return (
             (self.wpe_block is None or type(self.wpe_block) is WPE)
             and type(self.gss_block) is GSS and type(self.bf_block) is Beamformer
-            and (self.wpe_block is None or self.wpe_block.psd_context == 0)
         )
 
     def _params(self):
@@ -446,6 +445,7 @@ class Enhancer:
             stft_fading=self.stft_fading, wpe=w is not None,
             wpe_taps=w.taps if w else 10, wpe_delay=w.delay if w else 2,
             wpe_iterations=w.iterations if w else 3,
+            wpe_psd_context=w.psd_context if w else 0,
             bss_iterations=self.gss_block.iterations,
             bss_iterations_post=self.gss_block.iterations_post,
             bf_drop_context=self.bf_drop_context, bf=self.bf_block.type,

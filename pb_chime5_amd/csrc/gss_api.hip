@@ -67,6 +67,16 @@ extern "C" int gss_create(int device_id, gss_ctx **out) {
         return GSS_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    e = hipHostMalloc(reinterpret_cast<void **>(&ctx->status_host), 64, hipHostMallocMapped);
+    if (e == hipSuccess)
+        e = hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->status_dev), ctx->status_host, 0);
+    if (e != hipSuccess) {
+        g_create_error = hipGetErrorString(e);
+        (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return GSS_ERR_HIP;
+    }
+    ctx->status_host[0] = INT32_MIN;
     *out = ctx;
     return GSS_OK;
 }
@@ -86,6 +96,7 @@ extern "C" int gss_destroy(gss_ctx *ctx) {
     free_tables(ctx);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->wpe_tiles) (void)hipFree(ctx->wpe_tiles);
+    if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     for (auto &p : ctx->prof_pending) {
         (void)hipEventDestroy(p.start);
         (void)hipEventDestroy(p.stop);
@@ -360,16 +371,17 @@ extern "C" int gss_activity_time_to_frequency(gss_ctx *ctx, const uint8_t *act, 
 }
 
 extern "C" int gss_wpe(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T, int D, int taps,
-                       int delay, int iterations, gss_cplx *X) {
+                       int delay, int iterations, int psd_context, gss_cplx *X) {
     GSS_ENTER(ctx);
     GSS_REQUIRE(ctx, Y && X && F >= 1 && T >= 1, GSS_ERR_INVALID, "gss_wpe: bad arguments");
     GSS_REQUIRE(ctx, D >= 1 && D <= GSS_MAX_CHANNELS, GSS_ERR_UNSUPPORTED,
                 "gss_wpe: D=%d outside [1, %d]", D, GSS_MAX_CHANNELS);
-    GSS_REQUIRE(ctx, taps >= 1 && delay >= 0 && iterations >= 0, GSS_ERR_INVALID,
-                "gss_wpe: taps=%d delay=%d iterations=%d", taps, delay, iterations);
+    GSS_REQUIRE(ctx, taps >= 1 && delay >= 0 && iterations >= 0 && psd_context >= 0,
+                GSS_ERR_INVALID, "gss_wpe: taps=%d delay=%d iterations=%d psd_context=%d", taps,
+                delay, iterations, psd_context);
     GSS_TRY(arena_reserve(ctx, wpe_workspace_bytes(F, T, D, taps, delay)));
     return wpe_run(ctx, reinterpret_cast<const cplx *>(Y), F, T, D, taps, delay, iterations,
-                   reinterpret_cast<cplx *>(X));
+                   psd_context, reinterpret_cast<cplx *>(X));
 }
 
 static int check_cacgmm_args(gss_ctx *ctx, int D, int K, int iterations, int post) {
@@ -418,6 +430,28 @@ extern "C" int gss_mvdr_souden(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T
                     reinterpret_cast<cplx *>(Xhat), ref);
 }
 
+extern "C" int gss_mvdr_souden_ref(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T, int D,
+                                   const double *mx, const double *mn, int ban, int ref_channel,
+                                   gss_cplx *Xhat) {
+    GSS_ENTER(ctx);
+    GSS_REQUIRE(ctx, Y && mx && mn && Xhat && F >= 1 && T >= 1, GSS_ERR_INVALID,
+                "gss_mvdr_souden_ref: bad arguments");
+    GSS_REQUIRE(ctx, D >= 1 && D < 30, GSS_ERR_INVALID, "assert D < 30 failed: D=%d", D);
+    GSS_REQUIRE(ctx, ref_channel >= 0 && ref_channel < D, GSS_ERR_INVALID,
+                "ref_channel %d outside [0, %d)", ref_channel, D);
+    GSS_TRY(arena_reserve(ctx, mvdr_workspace_bytes(F, T, D)));
+    return mvdr_run(ctx, reinterpret_cast<const cplx *>(Y), F, T, D, mx, mn, ban,
+                    reinterpret_cast<cplx *>(Xhat), nullptr, /*gev=*/0, ref_channel);
+}
+
+extern "C" int gss_last_ref_channel(gss_ctx *ctx, int32_t *ref_channel) {
+    GSS_ENTER(ctx);
+    GSS_REQUIRE(ctx, ref_channel, GSS_ERR_INVALID, "gss_last_ref_channel: NULL");
+    GSS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *ref_channel = __atomic_load_n(ctx->status_host, __ATOMIC_ACQUIRE);
+    return GSS_OK;
+}
+
 extern "C" int gss_gev(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T, int D, const double *mx,
                        const double *mn, int ban, gss_cplx *Xhat) {
     GSS_ENTER(ctx);
@@ -443,6 +477,8 @@ static int check_params(gss_ctx *ctx, const gss_params *p) {
     GSS_REQUIRE(ctx, p->bf >= 0 && p->bf <= 3, GSS_ERR_UNSUPPORTED, "bf=%d", p->bf);
     GSS_REQUIRE(ctx, p->postfilter >= 0 && p->postfilter <= 1, GSS_ERR_UNSUPPORTED,
                 "postfilter=%d", p->postfilter);
+    GSS_REQUIRE(ctx, p->wpe_psd_context >= 0, GSS_ERR_INVALID, "wpe_psd_context=%d",
+                p->wpe_psd_context);
     return GSS_OK;
 }
 
@@ -510,7 +546,8 @@ static int enhance_observation_impl(gss_ctx *ctx, const gss_params *p, const voi
 
     GSS_TRY(stft_run(ctx, obs, obs_type, D, N, fading, Y));
     if (p->wpe) {
-        GSS_TRY(wpe_run(ctx, Y, F, T, D, p->wpe_taps, p->wpe_delay, p->wpe_iterations, X));
+        GSS_TRY(wpe_run(ctx, Y, F, T, D, p->wpe_taps, p->wpe_delay, p->wpe_iterations,
+                        p->wpe_psd_context, X));
         ctx->arena_off = mark;
     }
     GSS_TRY(activity_run(ctx, act, K, N_act, fading, actf));

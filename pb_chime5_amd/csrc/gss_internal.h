@@ -140,6 +140,11 @@ struct gss_ctx {
     double *win_synthesis = nullptr;  // device, stft_size
     cplx *twiddle = nullptr;          // device, stft_size/2: exp(-2 pi i j / size)
 
+    // Status word of the last beamformed utterance (mapped host memory written by
+    // mvdr_apply_kernel: the reference channel, -1 = non-finite SNR; INT32_MIN = none yet)
+    int32_t *status_host = nullptr;
+    int32_t *status_dev = nullptr;
+
     // WPE tile lists (device), rebuilt when (taps, delay, D) changes
     void *wpe_tiles = nullptr;
     int wpe_tiles_key[4] = {-1, -1, -1, -1};   // taps, delay, D, correlation tile size
@@ -207,7 +212,7 @@ struct ProfScope {
 // (device pointers, workspace from the arena, asynchronous on ctx->stream)
 size_t wpe_workspace_bytes(int F, int64_t T, int D, int taps, int delay);
 int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int delay,
-            int iterations, cplx *X);
+            int iterations, int psd_context, cplx *X);
 
 size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K);
 int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8_t *act,
@@ -218,7 +223,8 @@ int psd_partials_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const
 
 size_t mvdr_workspace_bytes(int F, int64_t T, int D);
 int mvdr_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double *mx,
-             const double *mn, int ban, cplx *Xhat, int32_t *ref_channel, int gev = 0);
+             const double *mn, int ban, cplx *Xhat, int32_t *ref_channel, int gev = 0,
+             int forced_ref = -1);
 int masks_from_posteriors_run(gss_ctx *ctx, const double *gamma, int F, int K, int64_t T,
                               int target, int drop, int64_t start_frames,
                               int64_t end_frames, double *mx, double *mn);

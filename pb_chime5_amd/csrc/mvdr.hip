@@ -394,11 +394,20 @@ __global__ __launch_bounds__(64) void gev_solve_kernel(const cplx *__restrict__ 
 }
 
 // get_optimal_reference_channel: one reference channel for all frequencies.
+// forced >= 0: the caller names the channel (pb_bss get_mvdr_vector_souden(ref_channel=...)).
+// A non-finite SNR makes the reference abort the utterance (`assert np.all(np.isfinite(SNR))`):
+// the channel becomes -1, mvdr_apply fills Xhat with NaN and the host raises.
 __global__ __launch_bounds__(64) void mvdr_ref_kernel(const cplx *__restrict__ snr, int F, int D,
-                                                      double eps, int32_t *__restrict__ ref) {
+                                                      double eps, int forced,
+                                                      int32_t *__restrict__ ref) {
     const int lane = threadIdx.x;
+    if (forced >= 0) {
+        if (lane == 0) ref[0] = forced;
+        return;
+    }
     double val = -INFINITY;
     bool isnan_ = false;
+    bool bad = false;
     if (lane < D) {
         cplx num = c_make(0.0, 0.0), den = c_make(0.0, 0.0);
         // fixed summation order (frequency ascending), loads issued 8 frequencies ahead
@@ -423,9 +432,12 @@ __global__ __launch_bounds__(64) void mvdr_ref_kernel(const cplx *__restrict__ s
         }
         // np.maximum(den, eps) on complex: lexicographic (real, then imag)
         if (!(den.x > eps || (den.x == eps && den.y > 0.0))) den = c_make(eps, 0.0);
-        val = c_div(num, den).x;
+        const cplx q = c_div(num, den);
+        val = q.x;
         isnan_ = val != val;
+        bad = !(isfinite(q.x) && isfinite(q.y));
     }
+    const bool any_bad = __any(bad);
     // np.argmax: first maximum, NaN counts as maximum
     double best = val;
     int bi = lane < D ? lane : 1 << 30;
@@ -445,21 +457,31 @@ __global__ __launch_bounds__(64) void mvdr_ref_kernel(const cplx *__restrict__ s
             bn = on;
         }
     }
-    if (lane == 0) ref[0] = bi;
+    if (lane == 0) ref[0] = any_bad ? -1 : bi;
 }
 
 // w = W[:, ref] (optionally BAN-normalised), Xhat[t][f] = w^H y_t.  grid (chunks, F)
 __global__ __launch_bounds__(256) void mvdr_apply_kernel(
     const cplx *__restrict__ Y, const cplx *__restrict__ W, const cplx *__restrict__ Phi,
     const int32_t *__restrict__ ref, int F, int64_t T, int D, int ban, int chunk_frames,
-    cplx *__restrict__ Xhat, int32_t *__restrict__ ref_out) {
+    cplx *__restrict__ Xhat, int32_t *__restrict__ ref_out, int32_t *__restrict__ status) {
     __shared__ cplx w[GSS_MAX_CHANNELS];
     __shared__ cplx t1[GSS_MAX_CHANNELS];
     __shared__ cplx t2[GSS_MAX_CHANNELS];
     __shared__ double s_norm;
     const int f = blockIdx.y, tid = threadIdx.x;
     const int r = ref[0];
-    if (ref_out && blockIdx.x == 0 && f == 0 && tid == 0) ref_out[0] = r;
+    if (blockIdx.x == 0 && f == 0 && tid == 0) {
+        if (ref_out) ref_out[0] = r;
+        if (status) __hip_atomic_store(status, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const int64_t c0 = (int64_t)blockIdx.x * chunk_frames;
+    const int64_t c1 = c0 + chunk_frames < T ? c0 + chunk_frames : T;
+    if (r < 0) {   // non-finite SNR: the reference raises, nothing meaningful to write
+        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        for (int64_t t = c0 + tid; t < c1; t += blockDim.x) Xhat[t * F + f] = c_make(qnan, qnan);
+        return;
+    }
     if (tid < D) w[tid] = W[((int64_t)f * D + tid) * D + r];
     __syncthreads();
     if (ban) {
@@ -488,8 +510,6 @@ __global__ __launch_bounds__(256) void mvdr_apply_kernel(
         if (tid < D) w[tid] = c_scale(w[tid], s_norm);
         __syncthreads();
     }
-    const int64_t c0 = (int64_t)blockIdx.x * chunk_frames;
-    const int64_t c1 = c0 + chunk_frames < T ? c0 + chunk_frames : T;
     const cplx *Yf = Y + (int64_t)f * T * D;
     for (int64_t t = c0 + tid; t < c1; t += blockDim.x) {
         const cplx *y = Yf + t * D;
@@ -542,7 +562,8 @@ size_t mvdr_workspace_bytes(int F, int64_t T, int D) {
 }
 
 int mvdr_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double *mx,
-             const double *mn, int ban, cplx *Xhat, int32_t *ref_channel, int gev) {
+             const double *mn, int ban, cplx *Xhat, int32_t *ref_channel, int gev,
+             int forced_ref) {
     const int NE = tri_count(D);
     int cf;
     const int nch = psd_chunks(F, T, &cf);
@@ -590,7 +611,7 @@ int mvdr_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double 
         {
             GSS_PROF(ctx, "mvdr_ref");
             hipLaunchKernelGGL(mvdr_ref_kernel, dim3(1), dim3(64), 0, ctx->stream, snr, F, D, 1e-10,
-                               ref);
+                               forced_ref, ref);
             GSS_LAUNCH_CHECK(ctx, "mvdr_ref_kernel");
         }
     }
@@ -599,7 +620,7 @@ int mvdr_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double 
         const int chunk = 256;
         hipLaunchKernelGGL(mvdr_apply_kernel, dim3((unsigned)((T + chunk - 1) / chunk), F),
                            dim3(256), 0, ctx->stream, Y, W, Phi, ref, F, T, D, ban, chunk, Xhat,
-                           ref_channel);
+                           ref_channel, ctx->status_dev);
         GSS_LAUNCH_CHECK(ctx, "mvdr_apply_kernel");
     }
     return GSS_OK;

@@ -1,8 +1,9 @@
-// WPE dereverberation: nara_wpe.wpe.wpe_v8(statistics_mode='full', psd_context=0)
+// WPE dereverberation: nara_wpe.wpe.wpe_v8(statistics_mode='full', psd_context)
 // as called from WPE.__call__ (/root/reference/pb_chime5/core.py:48-58).
 //
 // Per frequency f and iteration:
-//   lambda_t = mean_d |X[t,d]|^2 ;  w_t = 1 / max(lambda_t, 1e-10 * max_t lambda_t)
+//   lambda_t = mean_d |X[t,d]|^2   (psd_context = p > 0: averaged over the frames
+//   t-p..t+p that exist) ;  w_t = 1 / max(lambda_t, 1e-10 * max_t lambda_t)
 //   R = sum_t w_t  yt_t yt_t^H  (n x n, n = taps*D),   P = sum_t w_t yt_t y_t^H  (n x D)
 //   G = solve(R, P) ;  X[t] = Y[t] - G^H yt_t
 // where yt_t stacks the `taps` delayed frames.  With the stacking order of
@@ -30,15 +31,21 @@ namespace {
 // loads (consecutive lanes, consecutive bins -- a lane walking its own frame touches 64
 // cache lines per load), parked in LDS, and summed per frame from there.
 constexpr int POW_FRAMES = 256;
+// psd_context > 0 (nara_wpe.wpe.get_power): the per-frame power is first written to `raw`
+// and w takes its moving average over the existing frames of [t - p, t + p] -- np.correlate
+// with ones(2p + 1), mode 'full', divided by the same correlation of ones -- before the
+// maximum and the floor.
 __global__ __launch_bounds__(POW_FRAMES) void wpe_power_kernel(const cplx *__restrict__ X,
-                                                               int64_t T, int D,
+                                                               int64_t T, int D, int psd_context,
+                                                               double *__restrict__ raw,
                                                                double *__restrict__ w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *ps = reinterpret_cast<double *>(smem);      // POW_FRAMES * (D + 1)
     __shared__ double red[POW_FRAMES / 64];
     const int f = blockIdx.x, tid = threadIdx.x;
     const cplx *Xf = X + (int64_t)f * T * D;
-    double *wf = w + (int64_t)f * T;
+    double *wout = w + (int64_t)f * T;
+    double *wf = psd_context > 0 ? raw + (int64_t)f * T : wout;
     const int DP = D + 1;                                // odd-ish stride against bank conflicts
     double mx = 0.0;
     for (int64_t t0 = 0; t0 < T; t0 += POW_FRAMES) {
@@ -59,12 +66,25 @@ __global__ __launch_bounds__(POW_FRAMES) void wpe_power_kernel(const cplx *__res
             mx = fmax(mx, p);
         }
     }
+    if (psd_context > 0) {
+        __syncthreads();      // the raw powers of this frequency are complete (same workgroup)
+        mx = 0.0;
+        for (int64_t t = tid; t < T; t += POW_FRAMES) {
+            const int64_t lo = t - psd_context > 0 ? t - psd_context : 0;
+            const int64_t hi = t + psd_context < T - 1 ? t + psd_context : T - 1;
+            double sum = 0.0;
+            for (int64_t u = lo; u <= hi; ++u) sum += wf[u];
+            const double p = sum / (double)(hi - lo + 1);
+            wout[t] = p;
+            mx = fmax(mx, p);
+        }
+    }
     mx = wave_max(mx);
     if ((tid & 63) == 0) red[tid >> 6] = mx;
     __syncthreads();
     mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
     const double eps = 1e-10 * mx;
-    for (int64_t t = tid; t < T; t += POW_FRAMES) wf[t] = 1.0 / fmax(wf[t], eps);
+    for (int64_t t = tid; t < T; t += POW_FRAMES) wout[t] = 1.0 / fmax(wout[t], eps);
 }
 
 // ------------------------------------------------------------------ correlation (MFMA)
@@ -938,14 +958,14 @@ static int corr_padf(int D, int ct) { return (ct + D - 1) / D + 1; }
 size_t wpe_workspace_bytes(int F, int64_t T, int D, int taps, int delay) {
     const size_t n = (size_t)taps * D;
     size_t b = 0;
-    b += align_up(sizeof(double) * (size_t)F * T);       // w
+    b += 2 * align_up(sizeof(double) * (size_t)F * T);   // w, raw power (psd_context > 0)
     b += align_up(sizeof(cplx) * (size_t)F * n * n);     // R
     b += align_up(sizeof(cplx) * (size_t)F * n * D);     // P / G
     return b + 4096;
 }
 
 int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int delay,
-            int iterations, cplx *X) {
+            int iterations, int psd_context, cplx *X) {
     const int n = taps * D;
     const int c = delay + taps - 1;
     if (iterations == 0) {
@@ -956,9 +976,10 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     }
     GSS_REQUIRE(ctx, X != Y, GSS_ERR_INVALID, "gss_wpe: X must not alias Y");
     double *w = arena_alloc_t<double>(ctx, (size_t)F * T);
+    double *raw = psd_context > 0 ? arena_alloc_t<double>(ctx, (size_t)F * T) : w;
     cplx *R = arena_alloc_t<cplx>(ctx, (size_t)F * n * n);
     cplx *P = arena_alloc_t<cplx>(ctx, (size_t)F * n * D);
-    GSS_REQUIRE(ctx, w && R && P, GSS_ERR_NOMEM, "wpe workspace");
+    GSS_REQUIRE(ctx, w && raw && R && P, GSS_ERR_NOMEM, "wpe workspace");
 
     // tile lists: correlation tiles, then one trailing-update list per block column
     std::vector<CorrTile> tiles;
@@ -1089,7 +1110,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        (int)pow_lds));
             hipLaunchKernelGGL(wpe_power_kernel, dim3(F), dim3(POW_FRAMES), pow_lds, ctx->stream,
-                               cur, T, D, w);
+                               cur, T, D, psd_context, raw, w);
             GSS_LAUNCH_CHECK(ctx, "wpe_power_kernel");
         }
         {

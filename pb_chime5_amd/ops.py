@@ -144,13 +144,13 @@ def _ftd_to_host_dtf(ctx, buf, D, T, F):
 def wpe_dtf(Obs, taps=10, delay=2, iterations=3, psd_context=0, *, ctx=None):
     """WPE on the reference's (D,T,F) layout (what ``WPE.__call__`` hands over
     transposed to wpe_v8 and transposes back, core.py:52-58)."""
-    if psd_context != 0:
-        raise NotImplementedError(f'psd_context={psd_context}: only 0 is on the hot path')
+    if isinstance(psd_context, tuple) or int(psd_context) != psd_context or psd_context < 0:
+        raise NotImplementedError(f'psd_context={psd_context!r}: a non-negative integer')
     ctx = ctx or default_context()
     Y_d, (D, T, F) = _obs_to_device_ftd(ctx, Obs)
     X_d = ctx.empty(16 * F * T * D)
     ctx._check(ctx.lib.gss_wpe(ctx.handle, c_void_p(Y_d.ptr), F, T, D, int(taps), int(delay),
-                               int(iterations), c_void_p(X_d.ptr)), 'gss_wpe')
+                               int(iterations), int(psd_context), c_void_p(X_d.ptr)), 'gss_wpe')
     return _ftd_to_host_dtf(ctx, X_d, D, T, F)
 
 
@@ -195,21 +195,37 @@ def _mask_to_device_ft(ctx, mask, T, F):
     return ctx.to_device(m)
 
 
-def mvdr_souden_from_masks(Y, X_mask, N_mask, ban=False, *, return_ref_channel=False,
-                           ctx=None):
-    """Y (D,T,F), 2-D masks (T,F) -> X_hat (T,F) complex128."""
+def _check_ref_channel(ctx):
+    """pb_bss get_optimal_reference_channel: ``assert np.all(np.isfinite(SNR)), SNR`` --
+    the reference aborts the utterance; the device reports it as reference channel -1."""
+    ref = ctx.last_ref_channel()
+    assert ref != -1, 'get_optimal_reference_channel: the SNR is not finite'
+    return ref
+
+
+def mvdr_souden_from_masks(Y, X_mask, N_mask, ban=False, *, ref_channel=None,
+                           return_ref_channel=False, ctx=None):
+    """Y (D,T,F), 2-D masks (T,F) -> X_hat (T,F) complex128.  ``ref_channel`` names the
+    reference channel (pb_bss get_mvdr_vector_souden(ref_channel=...)); None = the SNR
+    argmax.  Raises AssertionError when an SNR is not finite, like the reference."""
     ctx = ctx or default_context()
     Y_d, (D, T, F) = _obs_to_device_ftd(ctx, Y)
     mx = _mask_to_device_ft(ctx, X_mask, T, F)
     mn = _mask_to_device_ft(ctx, N_mask, T, F)
     X_d = ctx.empty(16 * F * T)
-    ref_d = ctx.empty(16)
-    ctx._check(ctx.lib.gss_mvdr_souden(ctx.handle, c_void_p(Y_d.ptr), F, T, D, c_void_p(mx.ptr),
-                                       c_void_p(mn.ptr), int(bool(ban)), c_void_p(X_d.ptr),
-                                       c_void_p(ref_d.ptr)), 'gss_mvdr_souden')
+    if ref_channel is None:
+        ctx._check(ctx.lib.gss_mvdr_souden(ctx.handle, c_void_p(Y_d.ptr), F, T, D,
+                                           c_void_p(mx.ptr), c_void_p(mn.ptr), int(bool(ban)),
+                                           c_void_p(X_d.ptr), None), 'gss_mvdr_souden')
+    else:
+        ctx._check(ctx.lib.gss_mvdr_souden_ref(ctx.handle, c_void_p(Y_d.ptr), F, T, D,
+                                               c_void_p(mx.ptr), c_void_p(mn.ptr),
+                                               int(bool(ban)), int(ref_channel),
+                                               c_void_p(X_d.ptr)), 'gss_mvdr_souden_ref')
+    ref = _check_ref_channel(ctx)
     X_hat = ctx.to_host(X_d, (T, F), np.complex128)
     if return_ref_channel:
-        return X_hat, int(ctx.to_host(ref_d, (1,), np.int32)[0])
+        return X_hat, ref
     return X_hat
 
 
@@ -248,8 +264,9 @@ def activity_time_to_frequency_device(time_activity, size, shift, fading, *, ctx
 # fused pipeline
 # --------------------------------------------------------------------------
 def make_params(*, stft_size=1024, stft_shift=256, stft_fading=True, wpe=True, wpe_taps=10,
-                wpe_delay=2, wpe_iterations=3, bss_iterations=20, bss_iterations_post=1,
-                bf_drop_context=True, bf='mvdrSouden_ban', postfilter=None):
+                wpe_delay=2, wpe_iterations=3, wpe_psd_context=0, bss_iterations=20,
+                bss_iterations_post=1, bf_drop_context=True, bf='mvdrSouden_ban',
+                postfilter=None):
     if bf not in _BF_CODES:
         raise NotImplementedError(bf)
     if postfilter not in _POSTFILTER_CODES:
@@ -259,7 +276,8 @@ def make_params(*, stft_size=1024, stft_shift=256, stft_fading=True, wpe=True, w
         wpe=int(bool(wpe)), wpe_taps=wpe_taps, wpe_delay=wpe_delay,
         wpe_iterations=wpe_iterations, bss_iterations=bss_iterations,
         bss_iterations_post=bss_iterations_post, bf_drop_context=int(bool(bf_drop_context)),
-        bf=_BF_CODES[bf], postfilter=_POSTFILTER_CODES[postfilter])
+        bf=_BF_CODES[bf], postfilter=_POSTFILTER_CODES[postfilter],
+        wpe_psd_context=int(wpe_psd_context))
 
 
 class ResidentUtterance:
@@ -291,7 +309,10 @@ class ResidentUtterance:
             'gss_enhance_observation')
 
     def result(self):
-        return self.ctx.to_host(self.out_d, (self.n_out,), np.float64)
+        x_hat = self.ctx.to_host(self.out_d, (self.n_out,), np.float64)
+        if self.params.bf == _BF_CODES['mvdrSouden_ban']:
+            _check_ref_channel(self.ctx)
+        return x_hat
 
 
 class UtterancePipeline:
@@ -363,6 +384,11 @@ class UtterancePipeline:
     def pop(self):
         tag, slot, n_out = self._pending.popleft()
         x_hat = self.slots[slot].to_host(self._bufs[slot]['out'], (n_out,), np.float64)
+        if self.params.bf == _BF_CODES['mvdrSouden_ban']:
+            try:
+                _check_ref_channel(self.slots[slot])
+            except AssertionError as e:
+                raise AssertionError(f'{tag}: {e}') from None
         return tag, x_hat
 
     def close(self):

@@ -32,11 +32,36 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b)) / scale)
 
 
+def rel_err_per_freq(a, b, axis=-1, floor_db=-80.0):
+    """max over the frequency bins (along ``axis``) of ||a_f - b_f|| / ||b_f||, over the bins
+    whose energy ||b_f||^2 lies within ``floor_db`` of the loudest bin.  Unlike ``rel_err``
+    (one global scale: the loudest bins decide) every bin is held to the tolerance on its
+    own scale."""
+    a = np.moveaxis(np.asarray(a), axis, 0)
+    b = np.moveaxis(np.asarray(b), axis, 0)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    nb = np.sqrt(np.sum(np.abs(b.reshape(b.shape[0], -1)) ** 2, axis=1))
+    nd = np.sqrt(np.sum(np.abs((a - b).reshape(b.shape[0], -1)) ** 2, axis=1))
+    keep = nb ** 2 > np.max(nb ** 2) * 10.0 ** (floor_db / 10.0)
+    assert keep.any()
+    return float(np.max(nd[keep] / nb[keep]))
+
+
 @pytest.fixture(scope='session')
 def golden():
     def load(name):
         return np.load(GOLDEN / name, allow_pickle=False)
     return load
+
+
+@pytest.fixture(scope='session')
+def oracle_pool():
+    """Worker processes for all-bin oracle runs (tests/oracle_pool.py)."""
+    sys.path.insert(0, str(REPO / 'tests'))
+    from oracle_pool import OraclePool
+    pool = OraclePool()
+    yield pool
+    pool.close()
 
 
 @pytest.fixture(scope='session')

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import gss_oracle as oracle
-from conftest import rel_err
+from conftest import rel_err, rel_err_per_freq
 
 pytestmark = pytest.mark.gpu
 
@@ -343,6 +343,88 @@ def test_config5_long_rttm_segment_gev_stagewise(gpu_ctx):
     assert det['Obs'].shape[:2] == (12, 7503)
 
 
+def _all_bins_vs_oracle(gpu_ctx, pool, u, *, bf='mvdrSouden_ban', bss_iterations=20):
+    """The whole utterance against the LITERAL oracle on ALL 513 bins (WPE and EM of the
+    oracle spread over worker processes), the oracle's own reference channel, no bin left
+    out: for scenes whose distortion PSD matrix is well conditioned in every bin."""
+    from pb_chime5_amd import ops
+    cs = u.ex['start_orig']['original']
+    ce = u.ex['end']['original'] - u.ex['end_orig']['original']
+    x_hat, det = ops.enhance_observation(u.obs, u.activity_array, u.target_index, cs, ce,
+                                         debug=True, ctx=gpu_ctx, bf=bf,
+                                         bss_iterations=bss_iterations)
+    want, wdet = oracle.enhance_observation(
+        u.obs, u.activity_array, u.target_index, u.ex, return_details=True, bf=bf,
+        bss_iterations=bss_iterations, gss_fn=pool.gss_block, wpe_fn=pool.wpe_block)
+    T = det['Obs'].shape[1]
+    assert np.array_equal(det['acitivity_freq'], wdet['activity_freq'][:, :T])
+    Yf = wdet['Obs'].transpose(2, 0, 1)
+    cond = np.linalg.cond(oracle.get_power_spectral_density_matrix(Yf, wdet['distortion_mask'].T))
+    print('cond(Phi_N): max %.3g median %.3g' % (cond.max(), np.median(cond)))
+    assert cond.max() < 1e6, cond.max()
+    errs = dict(
+        wpe=rel_err(det['Obs'], wdet['Obs']),
+        wpe_per_f=rel_err_per_freq(det['Obs'], wdet['Obs'], axis=-1),
+        masks=float(np.max(np.abs(det['posterior'] - np.where(
+            wdet['masks'] == 0, det['posterior'], wdet['masks'])))),
+        X_mag=rel_err(np.abs(det['X_hat']), np.abs(wdet['X_hat'])),
+        X_mag_per_f=rel_err_per_freq(np.abs(det['X_hat']), np.abs(wdet['X_hat']), axis=-1),
+        x=rel_err(x_hat, want))
+    print(errs)
+    if bf == 'mvdrSouden_ban':
+        assert det['ref_channel'] == wdet['ref_channel']
+        assert rel_err(det['X_hat'], wdet['X_hat']) < TOL_STFT_MAG
+        assert errs['x'] < TOL_STFT_MAG
+    assert errs['wpe'] < 1e-6 and errs['wpe_per_f'] < 1e-5
+    assert errs['X_mag'] < TOL_STFT_MAG and errs['X_mag_per_f'] < TOL_STFT_MAG
+    return det, wdet
+
+
+def test_config3_all_bins_literal_oracle_well_conditioned(gpu_ctx, oracle_pool):
+    """BASELINE configs[2] shape (24 ch, 34.7 s incl. 2 x 15 s context, T = 2169) with a
+    spatially diffuse background 6 dB below one talker, so that cond(Phi_N) < 1e6 in every
+    bin: all bins, literal oracle, oracle-chosen reference channel."""
+    from pb_chime5_amd import synthetic
+    n = 554490
+    iv = [(240000, n - 240000), (100000, 400000), (50000, 250000), (300000, 520000)]
+    u = synthetic.make_utterance(1000, 24, n, iv, start_context=240000, end_context=240000,
+                                 rir_taps=1024, noise=0.1, fast=True, diffuse_noise=0.5)
+    det, _ = _all_bins_vs_oracle(gpu_ctx, oracle_pool, u)
+    assert det['Obs'].shape == (24, 2169, 513)
+
+
+def test_config5_all_bins_literal_oracle_well_conditioned(gpu_ctx, oracle_pool):
+    """BASELINE configs[4] shape (120 s, 12 ch, T = 7503, 40 EM iterations, GEV + BAN) with the
+    same diffuse background: all bins against the literal oracle (the phase of a generalised
+    eigenvector is arbitrary upstream too, so magnitudes are compared)."""
+    from pb_chime5_amd import synthetic
+    sr = 16000
+    iv = [(50 * sr, 70 * sr), (10 * sr, 60 * sr), (40 * sr, 100 * sr), (65 * sr, 115 * sr)]
+    u = synthetic.make_utterance(5, 12, 120 * sr, iv, start_context=50 * sr, end_context=50 * sr,
+                                 noise=0.1, fast=True, diffuse_noise=0.5)
+    det, _ = _all_bins_vs_oracle(gpu_ctx, oracle_pool, u, bf='gev_ban', bss_iterations=40)
+    assert det['Obs'].shape == (12, 7503, 513)
+
+
+def test_fused_pipeline_with_wpe_psd_context(gpu_ctx):
+    """get_enhancer(wpe_psd_context=2) stays on the fused device pipeline and matches the
+    oracle; the block-by-block path agrees."""
+    from pb_chime5_amd import synthetic
+    from pb_chime5_amd.core import get_enhancer
+    u = synthetic.tiny(seed=21, num_channels=6, num_samples=24000, num_speakers=3, context=4096)
+    enh = get_enhancer(wpe_tabs=4, wpe_psd_context=2, bss_iterations=6)
+    assert enh._fusable()
+    got = enh.enhance_observation(u.obs, u.activity, u.speaker_id, ex=u.ex)
+    blocks = enh.enhance_observation(u.obs, u.activity, u.speaker_id, ex=u.ex, fused=False)
+    want = oracle.enhance_observation(u.obs, u.activity_array, u.target_index, u.ex, wpe_taps=4,
+                                      wpe_psd_context=2, bss_iterations=6,
+                                      gss_fn=oracle.gss_block_batched)
+    plain = oracle.enhance_observation(u.obs, u.activity_array, u.target_index, u.ex, wpe_taps=4,
+                                       bss_iterations=6, gss_fn=oracle.gss_block_batched)
+    assert rel_err(got, want) < 1e-5 and rel_err(blocks, got) < 1e-9
+    assert rel_err(plain, want) > 1e-3
+
+
 def test_config2_end_to_end_vs_oracle(gpu_ctx, config2_run):
     """The bench workload (BASELINE.json configs[1]) end to end against the oracle run on
     ALL 513 bins (about 90 s of CPU).  Measured: 3e-8 after WPE, 1e-5 on the enhanced
@@ -355,6 +437,11 @@ def test_config2_end_to_end_vs_oracle(gpu_ctx, config2_run):
     assert det['ref_channel'] == wdet['ref_channel']
     assert rel_err(np.abs(det['X_hat']), np.abs(wdet['X_hat'])) < TOL_STFT_MAG
     assert rel_err(x_hat, want) < TOL_STFT_MAG
+    # every frequency bin on its own scale (bins within 80 dB of the loudest): the global
+    # figure above is decided by the loudest bins
+    per_f = rel_err_per_freq(np.abs(det['X_hat']), np.abs(wdet['X_hat']), axis=-1)
+    print('config 2, worst bin: |X_hat| rel err', per_f)
+    assert per_f < TOL_STFT_MAG, per_f
 
 
 def test_config2_properties(gpu_ctx, config2_run):
@@ -374,6 +461,48 @@ def test_config2_properties(gpu_ctx, config2_run):
     # the target is enhanced relative to the interferers: output power in the
     # target-only region vs. the region where the target is silent
     assert np.std(x_hat) > 0
+
+
+# ---------------------------------------------------------------- reference channel
+REF_MISMATCHES = []
+
+
+def _oracle_snr(wdet):
+    """The per-channel SNR get_optimal_reference_channel maximises, from the oracle's PSDs."""
+    cov_x, cov_n = wdet['cov_x'], wdet['cov_n']
+    phi = oracle.stable_solve(cov_n, cov_x)
+    mat = phi / np.maximum(np.trace(phi, axis1=-1, axis2=-2)[..., None, None].real, 1e-10)
+    num = np.einsum('FdR,FdD,FDR->R', mat.conj(), cov_x, mat).real
+    den = np.einsum('FdR,FdD,FDR->R', mat.conj(), cov_n, mat).real
+    return num / np.maximum(den, 1e-10)
+
+
+def _check_ref_channel_or_tie(gpu_ctx, det, wdet, tag, well_conditioned=None):
+    """The reference channel is one integer and must equal the oracle's.  A different
+    channel is tolerated only as a certified tie -- the oracle's own SNRs of the two
+    candidates agree to 1e-9 relative, or the scene is degenerate (a noise PSD matrix that
+    is singular to rounding in some bin: the SNR sums are then decided by the rounding of
+    the solve in the reference as well) -- and even then the beamformer is still checked,
+    with the oracle's channel forced (gss_mvdr_souden_ref) on the GPU's own tensors.
+    Every mismatch is recorded; test_reference_channel_mismatches_are_rare bounds them."""
+    from pb_chime5_amd import ops
+    if det['ref_channel'] == wdet['ref_channel']:
+        return True
+    snr = _oracle_snr(wdet)
+    gap = abs(snr[det['ref_channel']] - snr.max()) / abs(snr.max())
+    cond = np.linalg.cond(wdet['cov_n'])
+    degenerate = bool(cond.max() > 1e10 or snr.max() > 1e12)
+    REF_MISMATCHES.append(dict(tag=tag, gpu=det['ref_channel'], oracle=wdet['ref_channel'],
+                               gap=float(gap), cond_max=float(cond.max())))
+    assert gap < 1e-9 or degenerate, (tag, det['ref_channel'], wdet['ref_channel'], gap, cond.max())
+    if well_conditioned is not None:
+        assert not well_conditioned, (tag, 'reference channel differs on a well-conditioned scene')
+    X_forced = ops.mvdr_souden_from_masks(det['Obs'], det['target_mask'], det['distortion_mask'],
+                                          ban=True, ref_channel=wdet['ref_channel'], ctx=gpu_ctx)
+    good = cond < 1e8
+    assert good.any(), tag
+    assert rel_err(np.abs(X_forced[:, good]), np.abs(wdet['X_hat'][:, good])) < TOL_STFT_MAG, tag
+    return False
 
 
 # ---------------------------------------------------------------- edge cases
@@ -434,15 +563,18 @@ def test_edge_all_zero_observation_gives_nan_like_reference(gpu_ctx):
     """Digital silence: PSD matrices are zero, solve falls back to lstsq -> w = 0, and
     BAN divides 0 / 0 (eps = 0 upstream), so the reference returns NaN everywhere.
     (With WPE switched on the reference does not get that far: 1 / max(0, 0) = inf
-    poisons R and np.linalg.eigh raises; the GPU path returns NaN there as well.)"""
+    poisons R and np.linalg.eigh raises; the GPU path raises as well, at the next place
+    the reference checks for finiteness.)"""
     from pb_chime5_amd import ops, synthetic
     u = synthetic.tiny(num_channels=3, num_samples=6000, num_speakers=2, context=512)
     u.obs[:] = 0
     got, det, want, wdet = _run_both(u, wpe=False, bss_iterations=2)
     assert np.all(np.isnan(want)) and np.all(np.isnan(got))
-    with_wpe = ops.enhance_observation(u.obs, u.activity_array, u.target_index, 512, 512,
-                                       wpe=True, wpe_taps=2, bss_iterations=2)
-    assert np.all(np.isnan(with_wpe))
+    # with WPE the NaN reaches the SNRs of the reference-channel search, which the reference
+    # asserts to be finite (had it come that far)
+    with pytest.raises(AssertionError):
+        ops.enhance_observation(u.obs, u.activity_array, u.target_index, 512, 512,
+                                wpe=True, wpe_taps=2, bss_iterations=2)
 
 
 def test_edge_single_class_and_two_channels(gpu_ctx):
@@ -480,23 +612,15 @@ def test_other_channel_and_class_counts(gpu_ctx, D, K):
                                      bss_iterations=6)
     assert np.array_equal(det['acitivity_freq'], wdet['activity_freq'])
     assert rel_err(det['Obs'], wdet['Obs']) < 1e-5
-    if det['ref_channel'] != wdet['ref_channel']:
-        # the argmax over channels of a cross-frequency SNR sum: accept another channel only
-        # if the oracle's own SNRs are tied there to rounding, or degenerate (see _stagewise)
-        cov_x, cov_n = wdet['cov_x'], wdet['cov_n']
-        phi = oracle.stable_solve(cov_n, cov_x)
-        mat = phi / np.maximum(np.trace(phi, axis1=-1, axis2=-2)[..., None, None].real, 1e-10)
-        num = np.einsum('FdR,FdD,FDR->R', mat.conj(), cov_x, mat).real
-        den = np.einsum('FdR,FdD,FDR->R', mat.conj(), cov_n, mat).real
-        snr = num / np.maximum(den, 1e-10)
-        assert snr.max() > 1e12 or snr[det['ref_channel']] >= snr.max() * (1 - 1e-6), snr
-        return
+    _check_ref_channel_or_tie(gpu_ctx, det, wdet, (D, K))
     # one point source on 24 microphones (D, K = 24, 2) leaves the noise PSD matrix singular
     # to rounding in most bins (median cond 3e11, max 3e18): there the reference's own
     # output is decided by rounding, so the beamformer is compared where cond(Phi_N) < 1e8
     # (see _stagewise) and the time signal only when that is every bin
     strict = np.linalg.cond(wdet['cov_n']) < 1e8
     assert strict.mean() > 0.05, strict.mean()
+    if det['ref_channel'] != wdet['ref_channel']:
+        return          # a certified tie: X_hat was compared with the oracle's channel forced
     assert rel_err(np.abs(det['X_hat'][:, strict]), np.abs(wdet['X_hat'][:, strict])) < TOL_STFT_MAG
     if strict.all():
         assert rel_err(got, want) < TOL_STFT_MAG
@@ -646,9 +770,11 @@ def test_random_shapes_against_oracle(gpu_ctx):
         assert rel_err(det['Obs'], wdet['Obs']) < 1e-6, tag
         if bf == 'mvdrSouden_ban':
             # bins with a nearly singular Phi_N are decided by rounding in the reference too
-            good = np.linalg.cond(wdet['cov_n']) < 1e8
+            cond = np.linalg.cond(wdet['cov_n'])
+            good = cond < 1e8
             assert good.mean() > 0.5, tag
-            if det['ref_channel'] == wdet['ref_channel']:
+            if _check_ref_channel_or_tie(gpu_ctx, det, wdet, tag,
+                                         well_conditioned=bool(cond.max() < 1e8)):
                 assert rel_err(np.abs(det['X_hat'][:, good]), np.abs(wdet['X_hat'][:, good])) \
                     < TOL_STFT_MAG, tag
         else:
@@ -656,3 +782,12 @@ def test_random_shapes_against_oracle(gpu_ctx):
             assert rel_err(got, want) < TOL_STFT_MAG, tag
         done += 1
     assert done >= 15, done
+
+
+def test_reference_channel_mismatches_are_rare(gpu_ctx):
+    """Runs after the sweeps above (file order): how often did the GPU pick another
+    reference channel than the oracle?  Each case was already certified as a tie or a
+    degenerate scene and re-checked with the oracle's channel forced; on top of that they
+    must stay the exception."""
+    print('reference-channel mismatches:', REF_MISMATCHES)
+    assert len(REF_MISMATCHES) <= 3, REF_MISMATCHES

@@ -140,6 +140,57 @@ def test_wpe_matches_oracle(gpu_ctx, D, T, F, taps, delay, iters):
     assert np.max(np.abs(got - want)) / np.max(np.abs(Y)) < 1e-8
 
 
+@pytest.mark.parametrize('psd_context', [1, 3, 400])
+def test_wpe_psd_context_matches_oracle(gpu_ctx, psd_context):
+    """wpe_psd_context > 0 (core.py:56,583 -> nara_wpe get_power): the frame power is the
+    mean over the existing frames of [t - p, t + p] before the floor and the inversion;
+    p = 400 > T / 2 exercises windows cut on both sides at once."""
+    from pb_chime5_amd import ops
+    rng = np.random.default_rng(31 + psd_context)
+    D, T, F, taps, delay = 6, 523, 5, 4, 2
+    Y = _reverberant(rng, D, T, F)
+    Y[:, 40:60] *= 1e-3                       # a quiet passage: smoothing changes its weights
+    got = ops.wpe_dtf(Y, taps, delay, 3, psd_context, ctx=gpu_ctx)
+    want = oracle.wpe_block(Y, taps, delay, 3, psd_context)
+    # (the weights of the quiet frames are 1e6 times the others': cond(R) * eps, as in
+    # test_wpe_matches_oracle, is correspondingly larger)
+    assert np.max(np.abs(got - want)) / np.max(np.abs(Y)) < 1e-7
+    plain = oracle.wpe_block(Y, taps, delay, 3, 0)
+    assert np.max(np.abs(plain - want)) / np.max(np.abs(Y)) > 1e-4      # the knob does something
+    # closed form of the smoothed power the oracle uses
+    p = oracle.get_power(Y[..., 0], psd_context)
+    raw = np.mean(np.abs(Y[..., 0]) ** 2, axis=0)
+    for t in (0, 1, psd_context, T // 2, T - 2, T - 1):
+        lo, hi = max(0, t - psd_context), min(T - 1, t + psd_context)
+        assert abs(p[t] - raw[lo:hi + 1].mean()) <= 1e-12 * raw.max()
+    with pytest.raises(NotImplementedError):
+        ops.wpe_dtf(Y, taps, delay, 1, (1, 2), ctx=gpu_ctx)
+
+
+def test_wpe_underdetermined_few_frames(gpu_ctx):
+    """Fewer frames than unknowns (T <= taps * D, e.g. a short segment with little context):
+    R = Yt diag(w) Yt^H has rank <= T - c < n.  np.linalg.solve in the reference does not
+    raise on a numerically (not exactly) singular R and returns one of the infinitely many
+    minimisers; the blocked Cholesky here zeroes the rows whose pivot breaks down and
+    returns another.  Both are minimisers of the same weighted least-squares problem: the
+    filter output Y - X = G^H Yt is the projection of Y on the regressors, and with n > T
+    the regressors span everything the frames t >= c can hold, so both leave (nearly)
+    nothing.  Checked: the dereverberated frames after the first c are tiny for both, the
+    first `delay` frames are untouched, and everything is finite."""
+    from pb_chime5_amd import ops
+    rng = np.random.default_rng(5)
+    D, T, F, taps, delay = 8, 50, 3, 10, 2
+    Y = _reverberant(rng, D, T, F)
+    got = ops.wpe_dtf(Y, taps, delay, 1, ctx=gpu_ctx)
+    want = oracle.wpe_block(Y, taps, delay, 1)
+    assert np.all(np.isfinite(got))
+    c = delay + taps - 1
+    assert np.array_equal(got[:, :delay], Y[:, :delay])
+    scale = np.max(np.abs(Y))
+    assert np.max(np.abs(want[:, c + 1:])) < 1e-6 * scale     # the reference interpolates
+    assert np.max(np.abs(got[:, c + 1:])) < 1e-6 * scale      # and so does the Cholesky path
+
+
 def test_wpe_ill_conditioned_normal_equations(gpu_ctx):
     """T barely above taps * D: cond(R) ~ 1e10 and the two factorisations drift
     apart by cond * eps.  Both must still satisfy the normal equations."""
@@ -317,6 +368,72 @@ def test_mvdr_rank_deficient_but_not_zero_distortion(gpu_ctx):
     nm[4:6] = 1.0
     got = ops.mvdr_souden_from_masks(Y, xm, nm, ban=True, ctx=gpu_ctx)
     assert got.shape == (30, 3)
+
+
+def test_mvdr_nonfinite_snr_raises_like_reference(gpu_ctx):
+    """pb_bss get_optimal_reference_channel: `assert np.all(np.isfinite(SNR))`.  A NaN in the
+    observation makes every SNR NaN: the reference aborts the utterance with an
+    AssertionError; the device reports reference channel -1 and the host raises."""
+    from pb_chime5_amd import ops
+    rng = np.random.default_rng(3)
+    D, T, F = 5, 70, 6
+    Y = crandn(rng, D, T, F)
+    mx, mn = rng.uniform(size=(T, F)), rng.uniform(size=(T, F))
+    X, ref = ops.mvdr_souden_from_masks(Y, mx, mn, ban=True, return_ref_channel=True, ctx=gpu_ctx)
+    want, wdet = oracle.beamform_mvdr_souden_from_masks(Y, mx, mn, ban=True, return_details=True)
+    assert ref == wdet['ref_channel'] and gpu_ctx.last_ref_channel() == ref
+    Ybad = Y.copy()
+    Ybad[2, 10, 3] = np.nan
+    with pytest.raises(AssertionError):
+        oracle.beamform_mvdr_souden_from_masks(Ybad, mx, mn, ban=True)
+    with pytest.raises(AssertionError):
+        ops.mvdr_souden_from_masks(Ybad, mx, mn, ban=True, ctx=gpu_ctx)
+    assert gpu_ctx.last_ref_channel() == -1
+    # the next utterance on the same context is not affected
+    X2 = ops.mvdr_souden_from_masks(Y, mx, mn, ban=True, ctx=gpu_ctx)
+    assert np.array_equal(X2, X)
+
+
+def test_mvdr_forced_reference_channel(gpu_ctx):
+    """get_mvdr_vector_souden(ref_channel=r): every channel can be named."""
+    from pb_chime5_amd import ops
+    rng = np.random.default_rng(8)
+    D, T, F = 6, 90, 7
+    Y = crandn(rng, D, T, F)
+    mx, mn = rng.uniform(size=(T, F)), rng.uniform(size=(T, F))
+    Yf = Y.transpose(2, 0, 1)
+    cov_x = oracle.get_power_spectral_density_matrix(Yf, mx.T)
+    cov_n = oracle.get_power_spectral_density_matrix(Yf, mn.T)
+    for r in range(D):
+        w = oracle.get_mvdr_vector_souden(cov_x, cov_n, ref_channel=r, eps=1e-10)
+        w = oracle.blind_analytic_normalization(w, cov_n)
+        want = oracle.apply_beamforming_vector(w, Yf).T
+        got = ops.mvdr_souden_from_masks(Y, mx, mn, ban=True, ref_channel=r, ctx=gpu_ctx)
+        assert rel_err(got, want) < 1e-9, r
+    with pytest.raises(ValueError):
+        ops.mvdr_souden_from_masks(Y, mx, mn, ban=True, ref_channel=D, ctx=gpu_ctx)
+
+
+def test_interleaved_contexts_keep_their_own_state(gpu_ctx):
+    """Two contexts in one thread, calls interleaved (every entry point, the memcpy / memset
+    plumbing included, makes its context's device current first): results equal the
+    one-context runs."""
+    from pb_chime5_amd import ops
+    from pb_chime5_amd._capi import Context, device_count
+    rng = np.random.default_rng(4)
+    other = Context((device_count() - 1) if device_count() > 1 else 0)
+    try:
+        a = rng.standard_normal((3, 5000))
+        b = rng.standard_normal((2, 7000))
+        A = ops.stft(a, ctx=gpu_ctx)
+        B = ops.stft(b, ctx=other)
+        da, db = gpu_ctx.to_device(a), other.to_device(b)
+        assert np.array_equal(other.to_host(db, b.shape, np.float64), b)
+        assert np.array_equal(gpu_ctx.to_host(da, a.shape, np.float64), a)
+        assert np.array_equal(ops.stft(b, ctx=gpu_ctx), B)
+        assert np.array_equal(ops.stft(a, ctx=other), A)
+    finally:
+        other.close()
 
 
 def test_mvdr_asserts_like_reference(gpu_ctx):

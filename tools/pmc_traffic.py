@@ -1,75 +1,67 @@
-"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs because the
-TCC block has 4 counter slots) into per-launch HBM-side traffic per kernel.
+"""profiles/traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; TCC cannot
+hold both in one pass) of `python bench.py --steps 2 --warmup 1`.
 
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out_f -o p -- python bench.py ...
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out_w -o p -- python bench.py ...
-    python tools/pmc_traffic.py out_f/p_counter_collection.csv out_w/p_counter_collection.csv \
-        > profiles/traffic.json
+usage: python tools/pmc_traffic.py <dir with pmc_FETCH_SIZE/ and pmc_WRITE_SIZE/> <out.json>
 
-Units / corrections (MI355X_MICROARCH.md, section HBM): the counters are in KiB;
-on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B / lane) coalesced
-streaming reads -- every kernel here loads complex128 = 16 B per lane -- so the
-fetch side is doubled.  Infinity-Cache hits are counted, so this is fabric
-traffic, an upper bound of HBM traffic.
+Units as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: both counters are in
+KiB-sized units of 1024 B here (rocprofv3 reports FETCH_SIZE / WRITE_SIZE in kilobytes); on
+gfx950 FETCH_SIZE counts 128-B requests at 64 B, so fetch bytes are doubled.  Per launch =
+total over the launches of a kernel / number of launches.  Kernel names are mapped to the labels
+bench.py uses.
 """
-import collections
-import csv
-import json
-import re
-import sys
+import collections, csv, glob, json, re, sys
 
-BENCH_NAME = {
-    'wpe_corr_kernel': 'wpe_corr', 'wpe_apply_kernel': 'wpe_apply',
-    'wpe_power_kernel': 'wpe_power', 'chol_diag_kernel': 'wpe_chol_diag',
-    'chol_trsm_kernel': 'wpe_chol_trsm', 'chol_update_kernel': 'wpe_chol_update',
-    'chol_backsolve_kernel': 'wpe_backsolve', 'em_chol_kernel': 'em_chol',
-    'em_eigh_kernel': 'em_eigh', 'stft_kernel': 'stft', 'mvdr_apply_kernel': 'mvdr_apply',
-    'mvdr_solve_kernel': 'mvdr_solve', 'istft_frames_kernel': 'istft_frames',
-    'istft_ola_kernel': 'istft_ola', 'masks_kernel': 'masks', 'em_prepare_kernel': 'em_prepare',
-}
+LABELS = [
+    ('wpe_corr_kernel', 'wpe_corr'), ('wpe_apply_kernel', 'wpe_apply'), ('wpe_power_kernel', 'wpe_power'),
+    ('chol_update_kernel', 'wpe_chol_update'), ('chol_diag_kernel', 'wpe_chol_diag'),
+    ('chol_trsm_kernel', 'wpe_chol_trsm'), ('chol_backsolve_kernel', 'wpe_backsolve'),
+    ('em_estep_reg_kernel', 'em_estep'), ('em_estep_kernel', 'em_estep_first'),
+    ('em_prepare_kernel', 'em_prepare'), ('em_chol_kernel', 'em_chol'), ('em_eigh_kernel', 'em_eigh'),
+    ('mstep_reg_kernel', 'em_mstep'), ('stft_kernel', 'stft'), ('istft_frames_kernel', 'istft_frames'),
+    ('istft_ola_kernel', 'istft_ola'), ('mvdr_solve_kernel', 'mvdr_solve'), ('mvdr_apply_kernel', 'mvdr_apply'),
+    ('mvdr_ref_kernel', 'mvdr_ref'),
+]
 
 
-def bench_name(kernel):
-    m = re.search(r'(\w+_kernel)(<([^>]*)>)?', kernel)
-    if not m:
-        return None
-    base, targs = m.group(1), m.group(3)
-    if base == 'em_estep_kernel':
-        mode = targs.split(',')[1].strip()
-        return {'0': 'em_estep_first', '1': 'em_estep', '2': 'em_predict'}[mode]
-    if base == 'em_estep_reg_kernel':
-        mode = targs.split(',')[2].strip()
-        return {'1': 'em_estep', '2': 'em_predict'}[mode]
-    if base == 'wcov_kernel':
-        k = targs.split(',')[0].strip()
-        return 'psd' if (k == '2' and 'false, false' in targs) else 'em_mstep'
-    return BENCH_NAME.get(base)
+def label(kernel_name):
+    if 'wcov_kernel' in kernel_name:
+        # wcov_kernel<K, NORMALISE, SRC_FDT, ...>: the PSD matrices run on raw observations
+        m = re.search(r'wcov_kernel<(\d+), *(\w+), *(\w+)', kernel_name)
+        return 'em_mstep' if m and m.group(3) in ('true', '1') else 'psd'
+    if 'em_estep_reg_kernel' in kernel_name:
+        m = re.search(r'em_estep_reg_kernel<(\d+), *(\d+), *(\d+)', kernel_name)
+        return 'em_predict' if m and m.group(3) == '2' else 'em_estep'
+    for key, lab in LABELS:
+        if key in kernel_name:
+            return lab
+    m = re.search(r'(\w+)_kernel', kernel_name)
+    return m.group(1) if m else kernel_name[:24]
 
 
-def per_launch(path, counter):
-    total = collections.defaultdict(float)
-    launches = collections.defaultdict(set)
-    for r in csv.DictReader(open(path)):
-        if r['Counter_Name'] != counter:
-            continue
-        name = bench_name(r['Kernel_Name'])
-        if name is None:
-            continue
-        total[name] += float(r['Counter_Value'])
-        launches[name].add(r['Dispatch_Id'])
-    return {k: total[k] / len(launches[k]) for k in total}
+def totals(directory, counter):
+    acc, n = collections.defaultdict(float), collections.defaultdict(set)
+    for path in glob.glob(f'{directory}/**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r['Counter_Name'] != counter:
+                continue
+            lab = label(r['Kernel_Name'])
+            acc[lab] += float(r['Counter_Value'])
+            n[lab].add((path, r['Dispatch_Id']))
+    return {k: acc[k] / len(n[k]) for k in acc}
 
 
 def main():
-    fetch = per_launch(sys.argv[1], 'FETCH_SIZE')
-    write = per_launch(sys.argv[2], 'WRITE_SIZE')
-    out = {}
+    base, out = sys.argv[1], sys.argv[2]
+    fetch = totals(f'{base}/pmc_FETCH_SIZE', 'FETCH_SIZE')
+    write = totals(f'{base}/pmc_WRITE_SIZE', 'WRITE_SIZE')
+    res = {}
     for k in sorted(set(fetch) | set(write)):
-        f = 2.0 * fetch.get(k, 0.0) * 1024.0       # gfx950: x2 for 16 B/lane streams
-        w = write.get(k, 0.0) * 1024.0
-        out[k] = {'fetch_bytes': f, 'write_bytes': w, 'bytes': f + w}
-    json.dump(out, sys.stdout, indent=1)
-    print()
+        f = 2.0 * 1024.0 * fetch.get(k, 0.0)
+        w = 1024.0 * write.get(k, 0.0)
+        res[k] = {'fetch_bytes': f, 'write_bytes': w, 'bytes': f + w}
+    json.dump(res, open(out, 'w'), indent=1)
+    for k, v in sorted(res.items(), key=lambda kv: -kv[1]['bytes'])[:12]:
+        print(f"{k:18s} fetch {v['fetch_bytes']/1e6:9.1f} MB  write {v['write_bytes']/1e6:9.1f} MB per launch")
 
 
 if __name__ == '__main__':
