@@ -52,6 +52,10 @@ class OraclePool:
     def __init__(self, workers=None, bins_per_job=12):
         self.workers = workers or max(1, min(14, usable_cpus() - 2))
         self.bins_per_job = bins_per_job
+        # the workers inherit the environment: pin their numeric libraries to one thread
+        # BEFORE they import NumPy (the initializer below runs after the import)
+        for var in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):
+            os.environ[var] = '1'
         self._ex = ProcessPoolExecutor(self.workers, mp_context=mp.get_context('spawn'),
                                        initializer=_init)
 
