@@ -88,7 +88,10 @@ __global__ __launch_bounds__(POW_FRAMES) void wpe_power_kernel(const cplx *__res
 }
 
 // ------------------------------------------------------------------ correlation (MFMA)
-constexpr int CORR_KT = 64;   // frames staged per chunk
+#ifndef GSS_CORR_KT
+#define GSS_CORR_KT 64
+#endif
+constexpr int CORR_KT = GSS_CORR_KT;   // frames staged per chunk
 constexpr int CORR_FINE_MAX_SUBTILES = 48;   // up to here (D <= 12 at 10 taps): one wave per 16 x 16 sub-tile
 
 struct CorrTile {
