@@ -140,7 +140,10 @@ __device__ __forceinline__ void corr_tile_body(
     // latency hides under the matrix work (elements beyond CORR_STG * 256 -- only for
     // very wide windows -- are staged synchronously).
     constexpr int NT = 64 * NW;              // threads of the workgroup
-    constexpr int CORR_STG = NW == 1 ? 8 : (TS == 1 ? 1024 : 2048) / NT;
+#ifndef GSS_CORR_STG_ELEMS
+#define GSS_CORR_STG_ELEMS 2048
+#endif
+    constexpr int CORR_STG = NW == 1 ? 8 : (TS == 1 ? 1024 : GSS_CORR_STG_ELEMS) / NT;
     const int total = frames_lds * D;
     cplx stg[CORR_STG];
     double stg_w = 0.0;
