@@ -889,12 +889,16 @@ size_t em_estep_lds(int D, int K) {
     return (b + 15) / 16 * 16;
 }
 
-int em_chunks(int F, int64_t T, int *chunk_frames) {
+int em_chunks(int F, int64_t T, int D, int *chunk_frames) {
     // enough workgroups to fill 256 CUs a few times over, whole tiles per chunk; every
     // chunk costs one set of partial covariances that the model update re-reads
-    // (measured on config 2: 4 / 6 / 8 chunks -> 21.30 / 21.23 / 21.68 ms per utterance)
+    // (measured on config 2: 4 / 6 / 8 chunks -> 21.30 / 21.23 / 21.68 ms per utterance).
+    // With few channels a tile carries little arithmetic and longer chunks win (M-step at
+    // T = 2172, workgroup targets 1536 / 3072: D = 4 0.0295 / 0.0359 ms, D = 12 0.1075 /
+    // 0.1228 ms; D = 20 and 24 are flat within 2 %).
     int64_t tiles = (T + EM_TILE - 1) / EM_TILE;
-    static const int target = getenv("GSS_EM_WGS") ? atoi(getenv("GSS_EM_WGS")) : 3072;
+    static const int forced = getenv("GSS_EM_WGS") ? atoi(getenv("GSS_EM_WGS")) : 0;
+    const int target = forced > 0 ? forced : (D <= 12 ? 1536 : 3072);
     int64_t want = (target + F - 1) / F;
     if (want < 1) want = 1;
     int64_t tiles_per_chunk = (tiles + want - 1) / want;
@@ -1062,7 +1066,7 @@ int psd_partials_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const
 size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K) {
     const size_t NE = tri_count(D);
     int cf;
-    const int nch = em_chunks(F, T, &cf);
+    const int nch = em_chunks(F, T, D, &cf);
     size_t b = 0;
     b += align_up(sizeof(cplx) * (size_t)F * NE * K);            // Mq
     b += 2 * align_up(sizeof(double) * (size_t)F * K);           // logdet, pi
@@ -1086,7 +1090,7 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     a.F = F;
     a.D = D;
     a.NE = NE;
-    a.nch = em_chunks(F, T, &a.chunk_frames);
+    a.nch = em_chunks(F, T, D, &a.chunk_frames);
     cplx *Mq = arena_alloc_t<cplx>(ctx, (size_t)F * NE * K);
     double *logdet = arena_alloc_t<double>(ctx, (size_t)F * K);
     double *pi = arena_alloc_t<double>(ctx, (size_t)F * K);
