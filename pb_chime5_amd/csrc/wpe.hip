@@ -914,6 +914,205 @@ __global__ __launch_bounds__(64 * NWV) void wpe_apply_kernel(const cplx *__restr
             }
 }
 
+// ------------------------------------------------------------------ apply, frame phases packed into N
+// The GEMM above has N = D channels: at D = 24 a quarter of its MFMAs work on the empty half of
+// the second column tile, at D = 4 three quarters on an almost empty first one.  Consecutive
+// frames read the SAME flat window shifted by D elements:
+//     pred[t + p][d] = sum_r conj(G[r][d]) Yflat[(t - c) D + r + p D]
+//                    = sum_k conj(G[k - p D][d]) Yflat[(t - c) D + k],     k = r + p D,
+// so PH consecutive frames share one A row (the window that starts at frame t, K' = n +
+// (PH - 1) D long) against a B operand of PH D columns, column p D + d holding G shifted down by
+// p D rows: N = 48 = 3 full tiles at D = 24 with PH = 2 (17.5 % fewer MFMAs), N = 16 at D = 4
+// with PH = 4 (a third of the MFMAs).  G is staged in LDS once per workgroup (the shifted
+// columns would otherwise be three operand loads per k-step from L1 -- the form that was
+// measured slower in round 1), the window as before; frame f of the window lives at
+// f DP + f / PH so that the rows of a fragment (frames PH i) are an odd number of elements
+// apart.  grid (ceil(T / (64 PH)), F), block 256: one 16-row tile (16 PH frames) per wave.
+template <int PH, int NT>
+__global__ __launch_bounds__(256) void wpe_apply_packed_kernel(const cplx *__restrict__ Y,
+                                                               const cplx *__restrict__ G, int F,
+                                                               int64_t T, int D, int n, int c,
+                                                               cplx *__restrict__ X) {
+    constexpr int WG_ROWS = 64, WG_FRAMES = PH * WG_ROWS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int DP = D | 1, DG = D | 1;
+    const int frames_lds = WG_FRAMES + c + 2;
+    cplx *S = reinterpret_cast<cplx *>(smem);                   // frames_lds * DP + frames_lds / PH + 1
+    cplx *Gs = S + (frames_lds * DP + frames_lds / PH + 1);     // (n + 1) * DG, last row zeros
+    int f, chunk;
+    if (!xcd_group_map((int)((T + WG_FRAMES - 1) / WG_FRAMES), F, f, chunk)) return;
+    const int64_t t0 = (int64_t)chunk * WG_FRAMES;
+    const cplx *Yf = Y + (int64_t)f * T * D;
+    const cplx *Gf = G + (int64_t)f * n * D;
+    const int64_t fr0 = t0 - c;
+    constexpr int PRE = 14, NTHR = 256;
+    {   // window -> LDS (all loads of a batch in flight before the first store)
+        const int total = frames_lds * D;
+        for (int base = 0; base < total; base += NTHR * PRE) {
+            cplx v[PRE];
+#pragma unroll
+            for (int j = 0; j < PRE; ++j) {
+                const int idx = base + (int)threadIdx.x + NTHR * j;
+                const int64_t fr = fr0 + idx / D;
+                v[j] = c_make(0.0, 0.0);
+                if (idx < total && fr >= 0 && fr < T) v[j] = Yf[fr0 * D + idx];
+            }
+#pragma unroll
+            for (int j = 0; j < PRE; ++j) {
+                const int idx = base + (int)threadIdx.x + NTHR * j;
+                const int fl = idx / D, d = idx - fl * D;
+                if (idx < total) S[fl * DP + fl / PH + d] = v[j];
+            }
+        }
+    }
+    {   // G -> LDS
+        const int total = n * D;
+        for (int base = 0; base < total; base += NTHR * PRE) {
+            cplx v[PRE];
+#pragma unroll
+            for (int j = 0; j < PRE; ++j) {
+                const int idx = base + (int)threadIdx.x + NTHR * j;
+                v[j] = idx < total ? Gf[idx] : c_make(0.0, 0.0);
+            }
+#pragma unroll
+            for (int j = 0; j < PRE; ++j) {
+                const int idx = base + (int)threadIdx.x + NTHR * j;
+                const int r = idx / D, d = idx - r * D;
+                if (idx < total) Gs[r * DG + d] = v[j];
+            }
+        }
+        for (int d = threadIdx.x; d < DG; d += NTHR) Gs[n * DG + d] = c_make(0.0, 0.0);
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int row = 16 * wave + li;                         // A row of this lane: frames PH row + p
+    const int abase = row * (PH * DP + 1);                  // LDS address of frame PH row
+    const int Kp = n + (PH - 1) * D;
+    const int ksteps = (Kp + 3) / 4;
+    // column of this lane in tile b: col = 16 b + li = p D + d
+    int colp[NT], cold[NT];
+    bool colv[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int col = 16 * b + li;
+        colv[b] = col < PH * D;
+        colp[b] = colv[b] ? col / D : 0;
+        cold[b] = colv[b] ? col - colp[b] * D : 0;
+    }
+    v4d acc_re[NT], acc_t2[NT], acc_im[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        acc_re[b] = (v4d){0.0, 0.0, 0.0, 0.0};
+        acc_t2[b] = (v4d){0.0, 0.0, 0.0, 0.0};
+        acc_im[b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
+    // The k loop in three sections.  Head: k-steps that hold a k < (PH - 1) D (a shifted column
+    // has not started yet); tail: k-steps that hold a k >= n (the unshifted column has ended, the
+    // window operand may run past K'); body: every operand of every lane is valid and the
+    // addresses advance by constants -- no compare, no select, no division in between the MFMAs
+    // (with 153 KB of LDS one workgroup owns a CU: one wave per SIMD, and whatever VALU work sits
+    // between two groups of MFMAs is not hidden by anybody).  Columns past PH D (a partly
+    // filled last tile) read a row of zeros behind G with a zero address increment.
+    const int ks_head = min(((PH - 1) * D + 3) / 4, ksteps);
+    const int ks_tail = max(min(n / 4, ksteps), ks_head);
+    // k = 4 ks + lk = rq D + rm
+    int k = lk, rq = lk / D, rm = lk - rq * D;
+    auto u_addr = [&]() { return abase + rq * DP + rq / PH + rm; };
+    auto advance = [&]() {
+        k += 4;
+        rm += 4;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {   // D >= 1: at most 4 wraps, branch free
+            const bool wrap = rm >= D;
+            rm -= wrap ? D : 0;
+            rq += wrap ? 1 : 0;
+        }
+    };
+    auto mfma = [&](double ur, double ui, const double (&gr)[NT], const double (&gi)[NT]) {
+        const double us = ur + ui;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            acc_re[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ur, gr[b], acc_re[b], 0, 0, 0);
+            acc_t2[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui, gi[b], acc_t2[b], 0, 0, 0);
+            acc_im[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(us, gr[b] - gi[b], acc_im[b], 0, 0, 0);
+        }
+    };
+    // checked k-step (head and tail): validity by compare and select
+    auto checked_step = [&]() {
+        const bool ok = k < Kp;
+        const cplx u = S[ok ? u_addr() : abase];
+        double gr[NT], gi[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int kr = k - colp[b] * D;
+            const bool gv = colv[b] && kr >= 0 && kr < n;
+            const cplx g = Gs[(gv ? kr : 0) * DG + cold[b]];
+            gr[b] = gv ? g.x : 0.0;
+            gi[b] = gv ? g.y : 0.0;
+        }
+        mfma(ok ? u.x : 0.0, ok ? u.y : 0.0, gr, gi);
+        advance();
+    };
+    for (int ks = 0; ks < ks_head; ++ks) checked_step();
+    if (ks_tail > ks_head) {
+        // body: operands one k-step ahead, addresses by increments
+        int ga[NT], ginc[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            ga[b] = colv[b] ? (k - colp[b] * D) * DG + cold[b] : n * DG;     // row n of Gs: zeros
+            ginc[b] = colv[b] ? 4 * DG : 0;
+        }
+        cplx u_cur = S[u_addr()], g_cur[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) g_cur[b] = Gs[ga[b]];
+        for (int ks = ks_head; ks < ks_tail; ++ks) {
+            advance();
+            cplx u_nxt = u_cur, g_nxt[NT];
+            const bool more = ks + 1 < ks_tail;                 // uniform
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                ga[b] += ginc[b];
+                g_nxt[b] = g_cur[b];
+            }
+            if (more) {
+                u_nxt = S[u_addr()];
+#pragma unroll
+                for (int b = 0; b < NT; ++b) g_nxt[b] = Gs[ga[b]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            double gr[NT], gi[NT];
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                gr[b] = g_cur[b].x;
+                gi[b] = g_cur[b].y;
+            }
+            mfma(u_cur.x, u_cur.y, gr, gi);
+            __builtin_amdgcn_sched_barrier(0);
+            u_cur = u_nxt;
+#pragma unroll
+            for (int b = 0; b < NT; ++b) g_cur[b] = g_nxt[b];
+        }
+    }
+    for (int ks = ks_tail; ks < ksteps; ++ks) checked_step();
+    // C/D fragment: col = li, row = lk + 4 reg  ->  frame PH (16 wave + row) + p, channel d
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = 16 * wave + lk + 4 * reg;
+            const int fl = PH * r + colp[b];
+            const int64_t t = t0 + fl;
+            if (colv[b] && t < T) {
+                const int fw = fl + c;
+                const cplx y = S[fw * DP + fw / PH + cold[b]];
+                const double pre = acc_re[b][reg] + acc_t2[b][reg];
+                const double pim = (acc_im[b][reg] - acc_re[b][reg]) + acc_t2[b][reg];
+                X[((int64_t)f * T + t) * D + cold[b]] = c_make(y.x - pre, y.y - pim);
+            }
+        }
+}
+
 // ------------------------------------------------------------------ MFMA layout self-test
 __global__ void mfma_selftest_kernel(double *out) {
     // A[i][k] = i + 1 (k = 0 only), B[k][j] = 100 * (j + 1) (k = 0 only)
@@ -1095,6 +1294,46 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     if (apply_3m && apply_nwv == 3)
         apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, true, 3> : wpe_apply_kernel<apply_ta, 2, true, 3>;
     const size_t apply_lds = sizeof(cplx) * (size_t)(apply_frames + c + 2) * (D | 1);
+    // frame phases packed into the N dimension (wpe_apply_packed_kernel): pick the number of
+    // phases that minimises the MFMAs per frame, ceil(PH D / 16) (n + (PH - 1) D) / PH
+    int apply_ph = 1, apply_nt = (D + 15) / 16;
+    size_t packed_lds = 0;
+    {
+        const int ph_env = getenv("GSS_APPLY_PH") ? atoi(getenv("GSS_APPLY_PH")) : 0;   // tests
+        double best = (double)((D + 15) / 16) * n;
+        for (int ph = 2; ph <= 4; ++ph) {
+            if (ph_env > 0 && ph != ph_env) continue;
+            const int nt = (ph * D + 15) / 16;
+            if (nt > 3 || D < 2) continue;
+            const double cost = (double)nt * (n + (ph - 1) * D) / ph;
+            const int fl = 64 * ph + c + 2;
+            const size_t lds = sizeof(cplx) * ((size_t)fl * (D | 1) + fl / ph + 1 + (size_t)(n + 1) * (D | 1));
+            // (with G and the window in LDS only small channel counts keep two workgroups per CU;
+            // at D = 24 / 20 the packed form owns a CU alone, nothing overlaps its staging
+            // prologue, and it is slower: 1.82 vs 1.35 ms, 3.10 vs 2.28 ms per utterance)
+            if (lds > (ph_env == ph ? 160 : 64) * 1024) continue;
+            if (cost < 0.75 * best || ph_env == ph) {
+                best = cost;
+                apply_ph = ph;
+                apply_nt = nt;
+                packed_lds = lds;
+            }
+        }
+        if (ph_env == 1 || !apply_3m) apply_ph = 1;
+    }
+    using apply_packed_t = void (*)(const cplx *, const cplx *, int, int64_t, int, int, int, cplx *);
+    apply_packed_t packed_fn = nullptr;
+    if (apply_ph > 1) {
+        static const apply_packed_t table[3][3] = {
+            {wpe_apply_packed_kernel<2, 1>, wpe_apply_packed_kernel<2, 2>, wpe_apply_packed_kernel<2, 3>},
+            {wpe_apply_packed_kernel<3, 1>, wpe_apply_packed_kernel<3, 2>, wpe_apply_packed_kernel<3, 3>},
+            {wpe_apply_packed_kernel<4, 1>, wpe_apply_packed_kernel<4, 2>, wpe_apply_packed_kernel<4, 3>}};
+        packed_fn = table[apply_ph - 2][apply_nt - 1];
+        if (packed_lds > 64 * 1024)
+            GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(packed_fn),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)packed_lds));
+    }
     GSS_REQUIRE(ctx, corr_lds <= 160 * 1024 && apply_lds <= 160 * 1024, GSS_ERR_UNSUPPORTED,
                 "wpe: taps=%d D=%d needs more LDS than a CU has", taps, D);
     if (apply_lds > 64 * 1024)
@@ -1162,9 +1401,15 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         }
         {
             GSS_PROF(ctx, "wpe_apply");
-            hipLaunchKernelGGL(apply_fn,
-                               dim3(xcd_grid((int)((T + apply_frames - 1) / apply_frames), F)),
-                               dim3(64 * apply_nwv), apply_lds, ctx->stream, Y, P, F, T, D, n, c, X);
+            if (packed_fn) {
+                const int wg_frames = 64 * apply_ph;
+                hipLaunchKernelGGL(packed_fn, dim3(xcd_grid((int)((T + wg_frames - 1) / wg_frames), F)),
+                                   dim3(256), packed_lds, ctx->stream, Y, P, F, T, D, n, c, X);
+            } else {
+                hipLaunchKernelGGL(apply_fn,
+                                   dim3(xcd_grid((int)((T + apply_frames - 1) / apply_frames), F)),
+                                   dim3(64 * apply_nwv), apply_lds, ctx->stream, Y, P, F, T, D, n, c, X);
+            }
             GSS_LAUNCH_CHECK(ctx, "wpe_apply_kernel");
         }
     }

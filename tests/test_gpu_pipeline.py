@@ -669,7 +669,8 @@ def test_other_channel_and_class_counts(gpu_ctx, D, K):
 def test_kernel_variants_agree(gpu_ctx, D, monkeypatch):
     """The tuned kernel variants against their plain counterparts on the same input: 16 x 16
     vs 32 x 32 correlation tiles, 3- vs 4-product complex MFMA forms (correlation and filter
-    application), register-form vs tiled M-step (D = 4), register- vs LDS-form E-step,
+    application), the filter application with 1 - 4 frame phases packed into the column
+    dimension, register-form vs tiled M-step (D = 4), register- vs LDS-form E-step,
     Cholesky vs eigendecomposition model update.  Same arithmetic up to summation order."""
     from pb_chime5_amd import ops, synthetic
     # (frames per unknown and sensor noise as in test_other_channel_and_class_counts: a
@@ -693,7 +694,8 @@ def test_kernel_variants_agree(gpu_ctx, D, monkeypatch):
     assert good.mean() > 0.05, good.mean()
     for env in ({'GSS_CORR_TS': '2' if D <= 12 else '1'}, {'GSS_CORR_4M': '1', 'GSS_APPLY_4M': '1'},
                 {'GSS_MSTEP_TILED': '1'}, {'GSS_ESTEP_LDS': '1'}, {'GSS_FORCE_EIGH': '1'},
-                {'GSS_CORR_NW': '2'}, {'GSS_APPLY_NWV': '2'}):
+                {'GSS_CORR_NW': '2'}, {'GSS_APPLY_NWV': '2'}, {'GSS_APPLY_PH': '1'}, {'GSS_APPLY_PH': '2'},
+                {'GSS_APPLY_PH': '3'}, {'GSS_APPLY_PH': '4'}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         other, odet = run()
