@@ -137,3 +137,25 @@ def test_end_to_end_target_is_enhanced():
         gain_t = np.std(x_hat[:20000][tgt]) / np.std(u.obs[0][tgt])
         gain_i = np.std(x_hat[:20000][itf]) / np.std(u.obs[0][itf])
         assert gain_t > 1.5 * gain_i
+
+
+def test_wpe_psd_context_is_a_moving_average_over_existing_frames():
+    """nara_wpe.wpe.get_power(psd_context=p): np.correlate with ones(2p + 1) in 'full' mode cropped
+    to the centred lags, divided by the same correlation of ones -- i.e. the mean over the
+    frames of [t - p, t + p] that exist.  p = 0 is the plain frame power."""
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((5, 37)) + 1j * rng.standard_normal((5, 37))
+    raw = np.mean(np.abs(X) ** 2, axis=0)
+    assert np.allclose(oracle.get_power(X, 0), raw, rtol=0, atol=0)
+    for p in (1, 2, 18, 40):
+        got = oracle.get_power(X, p)
+        assert got.shape == raw.shape
+        for t in range(raw.size):
+            lo, hi = max(0, t - p), min(raw.size - 1, t + p)
+            assert abs(got[t] - raw[lo:hi + 1].mean()) <= 1e-13 * raw.max(), (p, t)
+        inv = oracle.get_power_inverse(X, p)
+        assert np.allclose(inv, 1 / np.maximum(got, 1e-10 * got.max()))
+    # the context changes the WPE result, zero context reproduces the default
+    Y = rng.standard_normal((3, 80)) + 1j * rng.standard_normal((3, 80))
+    assert np.array_equal(oracle.wpe_v6(Y, 3, 2, 2, 0), oracle.wpe_v6(Y, 3, 2, 2))
+    assert np.max(np.abs(oracle.wpe_v6(Y, 3, 2, 2, 2) - oracle.wpe_v6(Y, 3, 2, 2))) > 1e-6
