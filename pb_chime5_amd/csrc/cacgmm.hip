@@ -627,6 +627,26 @@ __device__ __forceinline__ void tri_unpack(int e, int D, int &d1, int &d2) {
     d2 = r + e - r * (2 * D - r + 1) / 2;
 }
 
+// (d1, d2) of the packed entries e = lane + 64 s a lane owns, unpacked once per kernel: the
+// class update walks them four times (trace, Frobenius norm, scatter to LDS, B^-1 product) and
+// the closed form costs a float square root and two corrections each time -- a sixth of the
+// instructions of em_chol, which is bound by instruction issue.
+struct TriSlots {
+    int d12[9];     // d1 << 8 | d2 for slot s (9 = COV_SLOTS below), -1 past the triangle
+};
+__device__ __forceinline__ TriSlots tri_slots(int D, int lane) {
+    TriSlots t;
+    const int NE = tri_count(D);
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        const int e = lane + 64 * s;
+        int d1 = 0, d2 = 0;
+        if (e < NE) tri_unpack(e, D, d1, d2);
+        t.d12[s] = e < NE ? (d1 << 8 | d2) : -1;
+    }
+    return t;
+}
+
 // sum over the E-step's partial sums of gamma_k: one load per lane and a fixed reduction
 // tree (a serial loop is a chain of dependent L2 round trips, one per partial sum).
 __device__ inline double sum_gamma(const double *__restrict__ Sg, int sg_nch, int K, int k, int f,
@@ -641,10 +661,11 @@ __device__ inline double sum_gamma(const double *__restrict__ Sg, int sg_nch, in
 // COV_SLOTS = ceil(528 / 64) of them).  All chunk loads of an entry are issued before
 // they are summed -- the reduction is otherwise a chain of dependent L2 round trips.
 constexpr int COV_SLOTS = 9;
+static_assert(COV_SLOTS == sizeof(TriSlots::d12) / sizeof(int), "TriSlots");
 
 __device__ inline double reduce_covariance(const cplx *__restrict__ Bp, int nch, int D, int K,
                                            int k, int f, double den, cplx (&vals)[COV_SLOTS],
-                                           int lane) {
+                                           int lane, const TriSlots &ts) {
     const int NE = tri_count(D);
     double tr = 0.0;
 #pragma unroll
@@ -669,14 +690,10 @@ __device__ inline double reduce_covariance(const cplx *__restrict__ Bp, int nch,
     // trace: diagonal entries
 #pragma unroll
     for (int s = 0; s < COV_SLOTS; ++s) {
-        const int e = lane + 64 * s;
-        if (e < NE) {
-            int d1, d2;
-            tri_unpack(e, D, d1, d2);
-            if (d1 == d2) {
-                vals[s].y = 0.0;
-                tr += vals[s].x;
-            }
+        const int p = ts.d12[s];
+        if (p >= 0 && (p >> 8) == (p & 255)) {
+            vals[s].y = 0.0;
+            tr += vals[s].x;
         }
     }
     return wave_sum(tr);
@@ -685,14 +702,12 @@ __device__ inline double reduce_covariance(const cplx *__restrict__ Bp, int nch,
 // Scatter the reduced entries into LDS: lower triangle (conjugated), optionally the
 // mirrored upper one, with `shift` subtracted from the diagonal.
 __device__ inline void store_covariance(const cplx (&vals)[COV_SLOTS], int D, double shift,
-                                        bool full, cplx *A, int ld, int lane) {
-    const int NE = tri_count(D);
+                                        bool full, cplx *A, int ld, int lane, const TriSlots &ts) {
 #pragma unroll
     for (int s = 0; s < COV_SLOTS; ++s) {
-        const int e = lane + 64 * s;
-        if (e < NE) {
-            int d1, d2;
-            tri_unpack(e, D, d1, d2);
+        const int p = ts.d12[s];
+        if (p >= 0) {
+            const int d1 = p >> 8, d2 = p & 255;
             cplx v = vals[s];
             if (d1 == d2) v.x -= shift;
             A[d2 * ld + d1] = c_conj(v);
@@ -725,22 +740,19 @@ template <int NR>
 __device__ __forceinline__ bool class_update_chol(const cplx (&vals)[COV_SLOTS], int D, int K,
                                                   double eig_floor, cplx *A, int lane,
                                                   cplx *__restrict__ Mq_fk,
-                                                  double *__restrict__ logdet_fk) {
+                                                  double *__restrict__ logdet_fk,
+                                                  const TriSlots &ts) {
     constexpr int ld = 8 * NR + 1;
-    const int NE = tri_count(D);
     double *dinv = reinterpret_cast<double *>(A + D * ld);
     double nb2 = 0.0;   // ||B||_F^2 from the packed upper triangle
 #pragma unroll
     for (int s = 0; s < COV_SLOTS; ++s) {
-        const int e = lane + 64 * s;
-        if (e < NE) {
-            int d1, d2;
-            tri_unpack(e, D, d1, d2);
-            nb2 += (d1 == d2 ? 1.0 : 2.0) * (vals[s].x * vals[s].x + vals[s].y * vals[s].y);
-        }
+        const int p = ts.d12[s];
+        if (p >= 0)
+            nb2 += ((p >> 8) == (p & 255) ? 1.0 : 2.0) * (vals[s].x * vals[s].x + vals[s].y * vals[s].y);
     }
     nb2 = wave_sum(nb2);
-    store_covariance(vals, D, 0.0, true, A, ld, lane);
+    store_covariance(vals, D, 0.0, true, A, ld, lane, ts);
     wave_sync();
     const int tx = lane & 7, ty = lane >> 3;
     cplx reg[NR][NR];
@@ -761,9 +773,11 @@ __device__ __forceinline__ bool class_update_chol(const cplx (&vals)[COV_SLOTS],
     //   = dinv[d2]^2 (d1 == d2 ? 1 : conj(A[d2][d1]))
     //     + sum_{j > d2} dinv[j]^2 conj(A[j][d1]) A[j][d2]
     double ni2 = 0.0;
-    for (int e = lane; e < NE; e += 64) {
-        int d1, d2;
-        tri_unpack(e, D, d1, d2);
+#pragma unroll
+    for (int s = 0; s < COV_SLOTS; ++s) {
+        const int p = ts.d12[s];
+        if (p < 0) continue;
+        const int e = lane + 64 * s, d1 = p >> 8, d2 = p & 255;
         const double s2 = dinv[d2] * dinv[d2];
         cplx v = d1 == d2 ? c_make(s2, 0.0) : c_scale(c_conj(A[d2 * ld + d1]), s2);
         for (int j = d2 + 1; j < D; ++j) {
@@ -793,14 +807,13 @@ __device__ __forceinline__ bool class_update_chol(const cplx (&vals)[COV_SLOTS],
 __device__ inline void class_update_eigh(const cplx (&vals)[COV_SLOTS], int D, int K,
                                          double eig_floor, cplx *A, int lane,
                                          cplx *__restrict__ Mq_fk,
-                                         double *__restrict__ logdet_fk) {
+                                         double *__restrict__ logdet_fk, const TriSlots &ts) {
     const int m = D + (D & 1);
-    const int NE = tri_count(D);
     cplx *V = A + m * m;
     double *lam = reinterpret_cast<double *>(V + m * m);
     for (int idx = lane; idx < m * m; idx += 64) A[idx] = c_make(0.0, 0.0);
     wave_sync();
-    store_covariance(vals, D, 0.0, true, A, m, lane);
+    store_covariance(vals, D, 0.0, true, A, m, lane, ts);
     wave_sync();
     jacobi_eigh_wave(A, V, m, lane, 20);
     double lmax = -INFINITY;
@@ -815,9 +828,11 @@ __device__ inline void class_update_eigh(const cplx (&vals)[COV_SLOTS], int D, i
     }
     ldv = wave_sum(ldv);
     wave_sync();
-    for (int e = lane; e < NE; e += 64) {
-        int d1, d2;
-        tri_unpack(e, D, d1, d2);
+#pragma unroll
+    for (int s = 0; s < COV_SLOTS; ++s) {
+        const int p = ts.d12[s];
+        if (p < 0) continue;
+        const int e = lane + 64 * s, d1 = p >> 8, d2 = p & 255;
         cplx v = c_make(0.0, 0.0);
         for (int j = 0; j < D; ++j) {
             const cplx a = V[d1 * m + j], b = V[d2 * m + j];
@@ -854,12 +869,13 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
     const double den = fmax(sg, GSS_TINY);
     if (lane == 0) pi[f * K + k] = sg / (double)T;
 
+    const TriSlots ts = tri_slots(D, lane);
     cplx vals[COV_SLOTS];
-    const double tr = reduce_covariance(Bp, nch, D, K, k, f, den, vals, lane);
+    const double tr = reduce_covariance(Bp, nch, D, K, k, f, den, vals, lane, ts);
     bool fast = !force_eigh && tr > 0.0 && isfinite(tr);
     if (fast)
         fast = class_update_chol<NR>(vals, D, K, eig_floor, A, lane, Mq + (int64_t)f * NE * K + k,
-                                     logdet + f * K + k);
+                                     logdet + f * K + k, ts);
     if (lane == 0) need_eigh[f * K + k] = fast ? 0 : 1;
 }
 
@@ -877,10 +893,11 @@ __global__ __launch_bounds__(64) void em_eigh_kernel(const cplx *__restrict__ Bp
     const int NE = tri_count(D);
     const double sg = sum_gamma(Sg, sg_nch, K, k, f, lane);
     const double den = fmax(sg, GSS_TINY);
+    const TriSlots ts = tri_slots(D, lane);
     cplx vals[COV_SLOTS];
-    reduce_covariance(Bp, nch, D, K, k, f, den, vals, lane);
+    reduce_covariance(Bp, nch, D, K, k, f, den, vals, lane, ts);
     class_update_eigh(vals, D, K, eig_floor, reinterpret_cast<cplx *>(smem), lane,
-                      Mq + (int64_t)f * NE * K + k, logdet + f * K + k);
+                      Mq + (int64_t)f * NE * K + k, logdet + f * K + k, ts);
 }
 
 size_t em_estep_lds(int D, int K) {
