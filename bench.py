@@ -255,10 +255,7 @@ class Config3Pool:
         from pb_chime5_amd import synthetic
         self.context = context
         self.core_max = 15 * SR
-        self.cores = []
-        for i in range(items):
-            rng = np.random.default_rng(1000 + i + 104729)
-            self.cores.append(int(np.clip(rng.lognormal(np.log(2.5), 0.7), 0.5, 15.0) * SR))
+        self.cores = [synthetic.config3_core_samples(i) for i in range(items)]
         self.num_samples = [c + 2 * context for c in self.cores]
         n = self.core_max + 2 * context
         self.bases = []

@@ -145,6 +145,14 @@ def config2(seed=2, num_channels=24, seconds=15.0, num_speakers=4):
                           start_context=ctx, end_context=ctx)
 
 
+def config3_core_samples(index):
+    """Core (utterance proper, without context) length in samples of dev-shaped item
+    ``index`` of BASELINE.json configs[2]: ~ LogNormal(ln 2.5 s, 0.7) clipped to
+    [0.5 s, 15 s], first draw of the item's generator (seed 1000 + index + 104729)."""
+    rng = np.random.default_rng(1000 + index + 104729)
+    return int(np.clip(rng.lognormal(np.log(2.5), 0.7), 0.5, 15.0) * SAMPLE_RATE)
+
+
 def config3_item(index, num_channels=24, context=240000):
     """BASELINE.json configs[2]: dev-shaped utterance number ``index`` (seed
     1000 + index); core length ~ LogNormal(ln 2.5 s, 0.7) clipped to
@@ -153,6 +161,7 @@ def config3_item(index, num_channels=24, context=240000):
     seed = 1000 + index
     rng = np.random.default_rng(seed + 104729)
     core = int(np.clip(rng.lognormal(np.log(2.5), 0.7), 0.5, 15.0) * sr)
+    assert core == config3_core_samples(index)
     n = core + 2 * context
     intervals = [(context, context + core)]
     for _ in range(3):

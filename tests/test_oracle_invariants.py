@@ -159,3 +159,16 @@ def test_wpe_psd_context_is_a_moving_average_over_existing_frames():
     Y = rng.standard_normal((3, 80)) + 1j * rng.standard_normal((3, 80))
     assert np.array_equal(oracle.wpe_v6(Y, 3, 2, 2, 0), oracle.wpe_v6(Y, 3, 2, 2))
     assert np.max(np.abs(oracle.wpe_v6(Y, 3, 2, 2, 2) - oracle.wpe_v6(Y, 3, 2, 2))) > 1e-6
+
+
+def test_config3_item_lengths_are_seeded():
+    """BASELINE configs[2]: the core lengths of the 512 dev-shaped items (what bench.py's sharded
+    session uses as costs and cuts its items to) come from the items' own seeds."""
+    from pb_chime5_amd import synthetic
+    cores = [synthetic.config3_core_samples(i) for i in range(512)]
+    assert cores[:3] == [synthetic.config3_core_samples(i) for i in range(3)]
+    assert min(cores) >= 8000 and max(cores) <= 240000
+    assert 30000 < np.median(cores) < 50000                     # median 2.5 s
+    frames = [(c + 480000 + 2 * 768 - 1024 + 255) // 256 + 1 for c in cores]
+    assert min(frames) >= 1906 and max(frames) <= 2816
+    assert len(set(cores)) > 500
