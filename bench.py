@@ -121,6 +121,32 @@ def _cpu_worker(job):
     out['cfg2_full_part_s'] = t_full
     out['cfg2_bins_part_s'] = t_bins
     out['cfg2_s'] = t_full + t_bins * F / float(sample_bins)
+    # ---- config 5 (120 s, 12 ch, 40 EM iterations, GEV + BAN): bin-sampled the same way
+    if 'obs5' in data.files:
+        del Obs, Xs, post, masks, X_hat
+        obs, act = data['obs5'], data['act5'].astype(bool)
+        ctx = int(data['ctx5'])
+        ex5 = dict(start={'original': 0}, start_orig={'original': ctx},
+                   end_orig={'original': obs.shape[1] - ctx}, end={'original': obs.shape[1]})
+        bins5 = np.linspace(0, F - 1, max(sample_bins // 3, 2)).astype(int)
+        t0 = time.perf_counter()
+        Obs = oracle.stft(obs)
+        act_f = oracle.activity_time_to_frequency(act, 1024, 256, True)
+        t_full = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        Xs = oracle.wpe_block(Obs[..., bins5], 10, 2, 3)
+        post = oracle.gss_block(Xs, act_f, 40, 1)
+        t_bins = time.perf_counter() - t0
+        masks = np.repeat(post[..., :1], F, axis=-1)
+        t0 = time.perf_counter()
+        sf, ef = oracle.start_end_context_frames(ex5, 1024, 256, True)
+        masks[:, :sf] = 0
+        masks[:, -ef:] = 0
+        X_hat = oracle.beamform_gev_from_masks(Obs, masks[0], np.sum(masks[1:], axis=0), ban=True)
+        oracle.istft(X_hat)
+        t_full += time.perf_counter() - t0
+        out['cfg5_s'] = t_full + t_bins * F / float(len(bins5))
+        out['cfg5_bins'] = int(len(bins5))
     return out
 
 
@@ -171,7 +197,7 @@ def _host_cpu():
     return model or 'unknown', physical, logical, mem_gb, quota
 
 
-def cpu_baseline(utt2, sample_bins=24, max_workers=None):
+def cpu_baseline(utt2, sample_bins=24, max_workers=None, with_config5=True):
     """the NumPy oracle (kind 'port') on W = physical cores - 1
     single-threaded worker processes, every worker enhancing whole utterances at the same
     time (so the figure includes what the cores cost each other in memory bandwidth)."""
@@ -186,14 +212,22 @@ def cpu_baseline(utt2, sample_bins=24, max_workers=None):
     if max_workers:
         W = max(1, min(W, max_workers))
     utt1 = synthetic.config1()
+    sr5 = SR
+    iv5 = [(50 * sr5, 70 * sr5), (10 * sr5, 60 * sr5), (40 * sr5, 100 * sr5), (65 * sr5, 115 * sr5)]
+    utt5 = synthetic.make_utterance(5, 12, 120 * sr5, iv5, start_context=50 * sr5,
+                                    end_context=50 * sr5, fast=True) if with_config5 else None
     saved = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS',
                                              'OPENBLAS_NUM_THREADS')}
     tmp = tempfile.NamedTemporaryFile(suffix='.npz', delete=False)
     tmp.close()
     try:
+        extra = {}
+        if utt5 is not None:
+            extra = dict(obs5=utt5.obs, act5=utt5.activity_array.astype(np.uint8),
+                         ctx5=utt5.ex['start_orig']['original'])
         np.savez(tmp.name, obs1=utt1.obs, act1=utt1.activity_array.astype(np.uint8),
                  obs2=utt2.obs, act2=utt2.activity_array.astype(np.uint8),
-                 ctx2=utt2.ex['start_orig']['original'])
+                 ctx2=utt2.ex['start_orig']['original'], **extra)
         for k in saved:
             os.environ[k] = '1'                  # inherited by the spawned workers
         t0 = time.perf_counter()
@@ -213,6 +247,13 @@ def cpu_baseline(utt2, sample_bins=24, max_workers=None):
                 os.environ[k] = v
     cfg1 = float(np.mean([r['cfg1_s'] for r in res]))
     cfg2 = float(np.mean([r['cfg2_s'] for r in res]))
+    config5 = None
+    if utt5 is not None:
+        cfg5 = float(np.mean([r['cfg5_s'] for r in res]))
+        config5 = {'per_core_value': utt5.seconds / cfg5, 'aggregate_value': W * utt5.seconds / cfg5,
+                   'seconds_per_utterance_per_core': cfg5,
+                   'sample': f'BASELINE configs[4] (120 s, 12 ch, 40 EM iterations, GEV + BAN), one segment '
+                             f'per worker, WPE + EM on {res[0]["cfg5_bins"]} of 513 bins, the rest in full'}
     return {
         'value': W * utt2.seconds / cfg2, 'unit': 'utterance-seconds/s', 'cores': W,
         'kind': 'port', 'cpu_model': model, 'physical_cores': physical,
@@ -223,6 +264,7 @@ def cpu_baseline(utt2, sample_bins=24, max_workers=None):
                     'seconds_per_utterance_per_core': cfg1,
                     'sample': 'BASELINE configs[0] (4 ch, 5 s, WPE off, 5 EM iterations), 2 whole '
                               'utterances per worker, nothing sampled'},
+        'config5': config5,
         'wall_s': wall,
         'sample': (f'{W} worker processes (usable physical cores - 1, like `mpiexec -np W+1`), each 1 '
                    f'thread, all running at the same time; per worker one config-2 utterance: '
