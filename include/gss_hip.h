@@ -63,6 +63,13 @@ typedef enum {
 #define GSS_MAX_CLASSES 8      /* pb_bss asserts K < 20; CHiME-5/6 use K <= 5           */
 #define GSS_MAX_STFT_SIZE 4096
 
+/* ABI revision of this header.  Bumped whenever an entry point changes its argument list
+ * or a struct its layout (round 2 added `psd_context` to gss_wpe and `wpe_psd_context` to
+ * gss_params: revision 2; round 3 added entry points only: revision 3).  A binder compares
+ * gss_abi_version() with the GSS_ABI_VERSION it was written against before any other call. */
+#define GSS_ABI_VERSION 3
+int gss_abi_version(void);
+
 /* ---- context ----------------------------------------------------------- */
 /* Number of visible HIP devices (0 if none / no driver).  Ranks of a node pick
  * LOCAL_RANK % gss_device_count() (pb_chime5_amd.parallel, replacing dlp_mpi's
@@ -173,6 +180,15 @@ int gss_mvdr_souden_ref(gss_ctx *ctx, const gss_cplx *Y_dev, int F, int64_t T, i
  * aborts the utterance with an AssertionError; here Xhat is filled with NaN and the host
  * raises.  INT32_MIN: no MVDR has run yet. */
 int gss_last_ref_channel(gss_ctx *ctx, int32_t *ref_channel_host);
+
+/* Number of pivots the WPE solve of the last gss_wpe / fused call on this context zeroed
+ * (summed over its iterations and frequencies; synchronises the stream).  The normal
+ * equations are solved by Cholesky; a non-positive pivot zeroes that row, which is the
+ * minimum-norm answer of stable_solve's lstsq fallback (math/solve.py:95-114) for an
+ * all-zero channel.  A count > 0 on live channels means R was rank deficient -- a segment
+ * with no more frames than taps * D unknowns -- where np.linalg.solve returns a different
+ * (equally arbitrary) minimiser than this library. */
+int gss_last_wpe_zero_pivots(gss_ctx *ctx, int64_t *count_host);
 
 /* beamform_gev_from_masks (beamforming_wrapper.py:77-89,192-208): masked PSD
  * matrices, principal generalised eigenvector of (Phi_X, Phi_N) with

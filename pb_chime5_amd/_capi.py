@@ -18,6 +18,7 @@ GSS_ERR_INVALID = -1
 GSS_ERR_HIP = -2
 GSS_ERR_NOMEM = -3
 GSS_ERR_UNSUPPORTED = -4
+GSS_ABI_VERSION = 3       # include/gss_hip.h revision these prototypes are written against
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -45,6 +46,7 @@ SIGNATURES = {
     'gss_destroy': (c_int, [c_void_p]),
     'gss_last_error': (ctypes.c_char_p, [c_void_p]),
     'gss_version': (ctypes.c_char_p, []),
+    'gss_abi_version': (c_int, []),
     'gss_set_stream': (c_int, [c_void_p, c_void_p]),
     'gss_synchronize': (c_int, [c_void_p]),
     'gss_dev_malloc': (c_int, [c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
@@ -76,6 +78,7 @@ SIGNATURES = {
     'gss_mvdr_souden_ref': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int,
                                     c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'gss_last_ref_channel': (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int32)]),
+    'gss_last_wpe_zero_pivots': (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int64)]),
     'gss_gev': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int,
                         c_void_p]),
     'gss_layout_dtf_to_ftd': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int,
@@ -115,6 +118,16 @@ def load_library(path=None):
             f'{p} is missing: build it with `python -m pb_chime5_amd.build` '
             '(there is no CPU fallback)')
     lib = ctypes.CDLL(str(p))
+    # the prototypes below are written against one revision of include/gss_hip.h: a library
+    # of another revision would read shifted arguments or a shorter gss_params
+    abi = getattr(lib, 'gss_abi_version', None)
+    got = None
+    if abi is not None:
+        abi.restype, abi.argtypes = c_int, []
+        got = int(abi())
+    if got != GSS_ABI_VERSION:
+        raise GssError(f'{p}: ABI revision {got}, this binding needs {GSS_ABI_VERSION} '
+                       '(rebuild with `python -m pb_chime5_amd.build --force`)')
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = restype
@@ -254,6 +267,14 @@ class Context:
         out = ctypes.c_int32()
         self._check(self.lib.gss_last_ref_channel(self.handle, ctypes.byref(out)),
                     'gss_last_ref_channel')
+        return int(out.value)
+
+    def last_wpe_zero_pivots(self):
+        """Pivots the WPE solve of the last call zeroed (synchronises); > 0 on live channels
+        means rank-deficient normal equations (T <= taps * D), see include/gss_hip.h."""
+        out = ctypes.c_int64()
+        self._check(self.lib.gss_last_wpe_zero_pivots(self.handle, ctypes.byref(out)),
+                    'gss_last_wpe_zero_pivots')
         return int(out.value)
 
     def workspace_bytes(self):

@@ -30,7 +30,9 @@ extern "C" const char *gss_last_error(gss_ctx *ctx) {
     return ctx->error.c_str();
 }
 
-extern "C" const char *gss_version(void) { return "pb_chime5_amd/libgss_hip 0.1 (gfx950, f64)"; }
+extern "C" const char *gss_version(void) { return "pb_chime5_amd/libgss_hip 0.3 (gfx950, f64)"; }
+
+extern "C" int gss_abi_version(void) { return GSS_ABI_VERSION; }
 
 // ------------------------------------------------------------------ context
 extern "C" int gss_device_count(void) {
@@ -77,6 +79,7 @@ extern "C" int gss_create(int device_id, gss_ctx **out) {
         return GSS_ERR_HIP;
     }
     ctx->status_host[0] = INT32_MIN;
+    ctx->status_host[2] = 0;
     *out = ctx;
     return GSS_OK;
 }
@@ -449,6 +452,14 @@ extern "C" int gss_last_ref_channel(gss_ctx *ctx, int32_t *ref_channel) {
     GSS_REQUIRE(ctx, ref_channel, GSS_ERR_INVALID, "gss_last_ref_channel: NULL");
     GSS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *ref_channel = __atomic_load_n(ctx->status_host, __ATOMIC_ACQUIRE);
+    return GSS_OK;
+}
+
+extern "C" int gss_last_wpe_zero_pivots(gss_ctx *ctx, int64_t *count) {
+    GSS_ENTER(ctx);
+    GSS_REQUIRE(ctx, count, GSS_ERR_INVALID, "gss_last_wpe_zero_pivots: NULL");
+    GSS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *count = __atomic_load_n(ctx->status_host + 2, __ATOMIC_ACQUIRE);
     return GSS_OK;
 }
 

@@ -140,8 +140,9 @@ struct gss_ctx {
     double *win_synthesis = nullptr;  // device, stft_size
     cplx *twiddle = nullptr;          // device, stft_size/2: exp(-2 pi i j / size)
 
-    // Status word of the last beamformed utterance (mapped host memory written by
-    // mvdr_apply_kernel: the reference channel, -1 = non-finite SNR; INT32_MIN = none yet)
+    // Status words (mapped host memory).  [0]: the last beamformed utterance, written by
+    // mvdr_apply_kernel: the reference channel, -1 = non-finite SNR; INT32_MIN = none yet.
+    // [2]: pivots zeroed by the last WPE call (copied from the device counter by wpe_run).
     int32_t *status_host = nullptr;
     int32_t *status_dev = nullptr;
 

@@ -344,7 +344,8 @@ constexpr int UD_LD = CH_NB + 1;   // LDS leading dimension of the diagonal bloc
 // Ud <- U_JJ (upper) and W = U_JJ^-H (strictly lower), dinv <- 1 / diag(U_JJ); both are
 // also written back to A.  The block lives in registers, 3 x 3 entries per thread, and
 // one pass of nb steps builds U and W together (chol_inverse_sweep in dense_wave.h).
-__device__ inline void chol_diag_block(cplx *A, int n, int j0, cplx *Ud, double *dinv) {
+__device__ inline void chol_diag_block(cplx *A, int n, int j0, cplx *Ud, double *dinv,
+                                       int32_t *zero_pivots) {
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int nb = min(CH_NB, n - j0);
     cplx reg[3][3];
@@ -355,7 +356,11 @@ __device__ inline void chol_diag_block(cplx *A, int n, int j0, cplx *Ud, double 
             const int i = ty + 16 * a, k = tx + 16 * b;
             reg[a][b] = (k >= i && k < nb) ? A[(int64_t)(j0 + i) * n + j0 + k] : c_make(0.0, 0.0);
         }
-    chol_inverse_sweep<16, 3>(reg, nb, Ud, UD_LD, dinv, tx, ty);
+    if (!chol_inverse_sweep<16, 3>(reg, nb, Ud, UD_LD, dinv, tx, ty)) {
+        // rows with a non-positive pivot were zeroed (the lstsq branch of stable_solve):
+        // counted for gss_last_wpe_zero_pivots()
+        if (tid < nb && dinv[tid] == 0.0) atomicAdd(zero_pivots, 1);
+    }
     // rows were published unscaled: scale them, fix the diagonal, clear the padding
     for (int idx = tid; idx < CH_NB * CH_NB; idx += blockDim.x) {
         const int i = idx / CH_NB, k = idx - i * CH_NB;
@@ -371,19 +376,28 @@ __device__ inline void chol_diag_block(cplx *A, int n, int j0, cplx *Ud, double 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void chol_diag_kernel(cplx *__restrict__ R, int n, int j0) {
+__global__ __launch_bounds__(256) void chol_diag_kernel(cplx *__restrict__ R, int n, int j0,
+                                                        int32_t *__restrict__ zero_pivots) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx *Ud = reinterpret_cast<cplx *>(smem);                       // CH_NB * UD_LD
     double *dinv = reinterpret_cast<double *>(Ud + CH_NB * UD_LD);   // CH_NB
-    chol_diag_block(R + (int64_t)blockIdx.x * n * n, n, j0, Ud, dinv);
+    chol_diag_block(R + (int64_t)blockIdx.x * n * n, n, j0, Ud, dinv, zero_pivots);
 }
 
-// Row panel on the MFMA: U_J[:, tile] = W A_J[:, tile] for one tile `ct` of 16 trailing
+// Row panel on the MFMA: U_J[:, tile] = U_JJ^-H A_J[:, tile] for one tile `ct` of 16 trailing
 // columns (tiles past the trailing block address the right-hand sides), by one wave.
-// The wave loads its nb x 16 block once (B operand, 12 k-steps), forms the three
-// 16-row output tiles (W is lower triangular: 4, 8 and 12 k-steps) and writes them
-// back in place.  W is read from the LDS copy of the diagonal block (strictly lower
-// part; the diagonal is taken from dinv, the upper part ignored).
+// Forward substitution in 16-row blocks with the EXPLICIT INVERSES OF THE 16 x 16 DIAGONAL
+// BLOCKS only (L = U_JJ^H, W_ii = L_ii^-1 from the sweep):
+//     X_0 = W_00 B_0,   X_1 = W_11 (B_1 - L_10 X_0),   X_2 = W_22 (B_2 - L_20 X_0 - L_21 X_1)
+// -- the same 24 k-steps as the product with the explicit 48 x 48 inverse that rounds 1-2
+// used, but backward stable like a triangular solve: the explicit 48 x 48 inverse costs a
+// factor cond(U_JJ) (3x the error of LAPACK on the bench workload, amplified 30x per WPE
+// iteration by the power weights; tests/golden/make_wpe_truth.py), a 16 x 16 one does not
+// show.  No data movement between the stages: the C fragment of v_mfma_f64_16x16x4_f64
+// (row = lk + 4 reg) IS the B operand sequence of the next product (k-step ks takes rows
+// 4 ks + lk, i.e. register ks).
+// The diagonal block comes from the LDS copy Ud: upper part U_JJ, strictly lower part W
+// (only its diagonal 16 x 16 blocks are used), 1 / U_ii from dinv.
 __device__ inline void chol_panel_tile(cplx *A, cplx *Z, int n, int D, int j0, int nb, int ct,
                                        const cplx *Ud, const double *dinv, int lane) {
     const int ntrail = n - j0 - nb;
@@ -407,22 +421,42 @@ __device__ inline void chol_panel_tile(cplx *A, cplx *Z, int n, int D, int j0, i
         const int row = 4 * ks + lk;
         bv[ks] = (row < nb && li < ncols) ? base[row * stride + li] : c_make(0.0, 0.0);
     }
-    v4d ore[3], oim[3];
+    v4d xre[3], xim[3];
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
-        ore[it] = (v4d){0.0, 0.0, 0.0, 0.0};
-        oim[it] = (v4d){0.0, 0.0, 0.0, 0.0};
+        // T = B_it - sum_{jt < it} L_it,jt X_jt   (L[i][k] = conj(U[k][i]))
+        v4d tre, tim;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            tre[r] = bv[4 * it + r].x;
+            tim[r] = bv[4 * it + r].y;
+        }
         const int i = 16 * it + li;
 #pragma unroll
-        for (int ks = 0; ks < 4 * (it + 1); ++ks) {
-            const int k = 4 * ks + lk;
+        for (int jt = 0; jt < it; ++jt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = 16 * jt + 4 * ks + lk;
+                const cplx u = Ud[k * UD_LD + i];
+                // T -= conj(u) x
+                tre = __builtin_amdgcn_mfma_f64_16x16x4f64(-u.x, xre[jt][ks], tre, 0, 0, 0);
+                tim = __builtin_amdgcn_mfma_f64_16x16x4f64(-u.x, xim[jt][ks], tim, 0, 0, 0);
+                tre = __builtin_amdgcn_mfma_f64_16x16x4f64(-u.y, xim[jt][ks], tre, 0, 0, 0);
+                tim = __builtin_amdgcn_mfma_f64_16x16x4f64(u.y, xre[jt][ks], tim, 0, 0, 0);
+            }
+        // X_it = W_ii T
+        xre[it] = (v4d){0.0, 0.0, 0.0, 0.0};
+        xim[it] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = 16 * it + 4 * ks + lk;
             cplx w = Ud[i * UD_LD + k];
             if (k == i) w = c_make(i < nb ? dinv[i] : 0.0, 0.0);
             if (k > i) w = c_make(0.0, 0.0);
-            ore[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, bv[ks].x, ore[it], 0, 0, 0);
-            oim[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, bv[ks].y, oim[it], 0, 0, 0);
-            ore[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(-w.y, bv[ks].y, ore[it], 0, 0, 0);
-            oim[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.y, bv[ks].x, oim[it], 0, 0, 0);
+            xre[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, tre[ks], xre[it], 0, 0, 0);
+            xim[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, tim[ks], xim[it], 0, 0, 0);
+            xre[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(-w.y, tim[ks], xre[it], 0, 0, 0);
+            xim[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.y, tre[ks], xim[it], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -430,7 +464,7 @@ __device__ inline void chol_panel_tile(cplx *A, cplx *Z, int n, int D, int j0, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * it + lk + 4 * r;
-            if (row < nb && li < ncols) base[row * stride + li] = c_make(ore[it][r], oim[it][r]);
+            if (row < nb && li < ncols) base[row * stride + li] = c_make(xre[it][r], xim[it][r]);
         }
 }
 
@@ -450,7 +484,8 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(cplx *__restrict__ R,
     if (!xcd_group_map((npanel + 3) / 4, F, f, grp)) return;
     cplx *A = R + (int64_t)f * n * n;
     cplx *Z = P + (int64_t)f * n * D;
-    // W block -> LDS: all 9 loads of a thread in flight before the first store
+    // diagonal block (U_JJ above, W below the diagonal) -> LDS: all 9 loads of a thread in
+    // flight before the first store
     constexpr int WL = CH_NB * CH_NB / 256;
     static_assert(WL * 256 == CH_NB * CH_NB, "block size");
     cplx wv[WL];
@@ -459,7 +494,7 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(cplx *__restrict__ R,
         const int idx = tid + 256 * s;
         const int i = idx / CH_NB, k = idx - i * CH_NB;
         wv[s] = c_make(0.0, 0.0);
-        if (i < nb && k <= i) wv[s] = A[(int64_t)(j0 + i) * n + j0 + k];
+        if (i < nb && k < nb) wv[s] = A[(int64_t)(j0 + i) * n + j0 + k];
     }
 #pragma unroll
     for (int s = 0; s < WL; ++s) {
@@ -596,21 +631,66 @@ __global__ __launch_bounds__(256) void chol_update_kernel(cplx *__restrict__ R,
                                        nb, tiles[tile_id], lane);
 }
 
-// Blocked back substitution U G = Z, G overwrites Z:  G_J = W_J^H (Z_J - U_J,>J G_>J),
-// J descending, both products on the f64 MFMA.  grid (F), block 256: waves 0..2 own
-// one 16-row tile of the 48-row block each (2 column tiles = 32 right-hand sides per
-// pass), so every frequency reads its U exactly once.
+// Blocked back substitution U G = Z, G overwrites Z:  G_J = U_JJ^-1 (Z_J - U_J,>J G_>J),
+// J descending, on the f64 MFMA.  grid (F), block 256.  Per block column: waves 0..2 own
+// one 16-row tile of S = Z_J - U_J,>J G_>J each (2 column tiles = 32 right-hand sides per
+// pass), so every frequency reads its U exactly once; wave 3 meanwhile parks the diagonal
+// block in LDS as ready-made A operands (6 blocks of 16 x 16 in fragment order).  Then waves
+// 3 and 2 take one column tile each through the 16-blocked back substitution with the
+// explicit inverses of the 16 x 16 diagonal blocks only (see chol_panel_tile: backward
+// stable, same MFMA count as the product with the explicit 48 x 48 inverse):
+//     X_2 = W_22^H S_2,  X_1 = W_11^H (S_1 - U_12 X_2),  X_0 = W_00^H (S_0 - U_01 X_1 - U_02 X_2)
 constexpr int BS_LD = 33;   // padded leading dimension of the LDS copy of S
+constexpr int BS_OPS = 6 * 4 * 64;   // A operands of the substitution: [block][k-step][lane]
 
-__device__ inline void chol_backsolve_body(const cplx *A, cplx *Z, int n, int D, cplx *S) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+__device__ inline void chol_backsolve_body(const cplx *A, cplx *Z, int n, int D, cplx *S,
+                                           cplx *OP) {
+    // (wave index in an SGPR: the roles below are separate paths of the control flow graph,
+    // so the registers of one do not stay allocated across the other)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
     const int nblk = (n + CH_NB - 1) / CH_NB;
     const int a = wave;                       // row tile of this wave (waves 0..2)
     for (int c0 = 0; c0 < D; c0 += 32) {      // 32 right-hand sides per pass
         for (int J = nblk - 1; J >= 0; --J) {
             const int j0 = J * CH_NB, nb = min(CH_NB, n - j0);
-            if (a < 3) {
+            if (a == 3) {
+                // A operands (lane li = row i within the tile, lk = k within the k-step):
+                //   blocks 0..2: (W_tt^H)[i][k] = conj(W[k][i]) (k > i), 1 / U_ii (k == i), 0 (k < i),
+                //                stored NEGATED;  blocks 3..5: U[i][k] of the tile pairs (1,2), (0,1), (0,2)
+                const cplx *Ad = A + (int64_t)j0 * n + j0;
+                auto fetch = [&](int row, int col) {      // unconditional, clamped
+                    const bool ok = row < nb && col < nb;
+                    const cplx v = Ad[(int64_t)(ok ? row : 0) * n + (ok ? col : 0)];
+                    return c_make(ok ? v.x : 0.0, ok ? v.y : 0.0);
+                };
+                cplx wop[3][4], uop[3][4];
+                double dg[3];
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) wop[it][ks] = fetch(16 * it + 4 * ks + lk, 16 * it + li);
+                    dg[it] = fetch(16 * it + li, 16 * it + li).x;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    uop[0][ks] = fetch(16 + li, 32 + 4 * ks + lk);
+                    uop[1][ks] = fetch(li, 16 + 4 * ks + lk);
+                    uop[2][ks] = fetch(li, 32 + 4 * ks + lk);
+                }
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const double ndinv = dg[it] > 0.0 ? -1.0 / dg[it] : 0.0;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int k = 4 * ks + lk;
+                        const cplx w = wop[it][ks];
+                        OP[(it * 4 + ks) * 64 + lane] =
+                            c_make(k == li ? ndinv : (k < li ? 0.0 : -w.x), k <= li ? 0.0 : -w.y);
+                        OP[((3 + it) * 4 + ks) * 64 + lane] = uop[it][ks];
+                    }
+                }
+            } else {
                 // ---- S = Z_J - U_J,>J G_>J  (rows j0 + 16a .., columns c0 .. c0+31)
                 v4d acc_re[2], acc_im[2];
 #pragma unroll
@@ -672,73 +752,68 @@ __device__ inline void chol_backsolve_body(const cplx *A, cplx *Z, int n, int D,
                             c_make(acc_re[b][reg], acc_im[b][reg]);
             }
             __syncthreads();
-            // W_J fragments for the product below, all requested at once (loaded inside its
-            // k loop, each of the up to 12 steps waited for a round trip)
-            cplx wall[CH_NB / 4];
-            if (a < 3) {
-                const int i = 16 * a + li;
+            const int b = 3 - a;                 // column tile of waves 3 and 2
+            if (a >= 2 && c0 + 16 * b < D) {
+                // ---- G_J = U_JJ^-1 S, rows 32.., 16.., 0..
+                // The MFMA only adds and a complex product needs one subtraction: the operands
+                // are stored so that it falls on the B side (4 sign flips per stage).
+                // Tn = -(S - U X):  Tn += u x ;  X = -conj(w) Tn, with p = -w stored
+                v4d xre[3], xim[3], nxim[3];
 #pragma unroll
-                for (int ks = 0; ks < CH_NB / 4; ++ks) {
-                    const int k = 4 * ks + lk;
-                    wall[ks] = c_make(0.0, 0.0);
-                    if (ks >= 4 * a && i < nb && k < nb && k >= i)
-                        wall[ks] = A[(int64_t)(j0 + k) * n + j0 + i];
-                }
-            }
-            if (a < 3) {
-                // ---- G_J = W^H S :  out[i][d] = sum_{k >= i} conj(W[k][i]) S[k][d],
-                // W[k][i] (k > i) sits at A[j0+k][j0+i], W[i][i] = 1 / U[i][i]
-                v4d acc_re[2], acc_im[2];
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    acc_re[b] = (v4d){0.0, 0.0, 0.0, 0.0};
-                    acc_im[b] = (v4d){0.0, 0.0, 0.0, 0.0};
-                }
-                const int i = 16 * a + li;
-#pragma unroll
-                for (int ks = 0; ks < CH_NB / 4; ++ks) {
-                    if (ks < 4 * a || ks >= (nb + 3) / 4) continue;     // wave uniform
-                    const int k = 4 * ks + lk;
-                    cplx w = c_make(0.0, 0.0);
-                    if (i < nb && k < nb) {
-                        if (k > i) {
-                            w = wall[ks];
-                        } else if (k == i) {
-                            const double d = wall[ks].x;
-                            w = c_make(d > 0.0 ? 1.0 / d : 0.0, 0.0);
-                        }
-                    }
-                    const double nwi = -w.y;
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const cplx s = k < nb ? S[k * BS_LD + 16 * b + li] : c_make(0.0, 0.0);
-                        // conj(w) * s
-                        acc_re[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, s.x, acc_re[b], 0, 0, 0);
-                        acc_im[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, s.y, acc_im[b], 0, 0, 0);
-                        acc_re[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.y, s.y, acc_re[b], 0, 0, 0);
-                        acc_im[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nwi, s.x, acc_im[b], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int st = 0; st < 3; ++st) {
+                    const int it = 2 - st;
+                    v4d tre, tim;
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        const int rl = 16 * a + lk + 4 * reg, col = c0 + 16 * b + li;
-                        if (rl < nb && col < D)
-                            Z[(int64_t)(j0 + rl) * D + col] =
-                                c_make(acc_re[b][reg], acc_im[b][reg]);
+                        const cplx sv = S[(16 * it + lk + 4 * reg) * BS_LD + 16 * b + li];
+                        tre[reg] = -sv.x;
+                        tim[reg] = -sv.y;
                     }
+#pragma unroll
+                    for (int sj = 0; sj < st; ++sj)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            const int jt = 2 - sj;
+                            const cplx u = OP[((3 + (it == 1 ? 0 : jt)) * 4 + ks) * 64 + lane];
+                            tre = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, xre[jt][ks], tre, 0, 0, 0);
+                            tim = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, xim[jt][ks], tim, 0, 0, 0);
+                            tre = __builtin_amdgcn_mfma_f64_16x16x4f64(u.y, nxim[jt][ks], tre, 0, 0, 0);
+                            tim = __builtin_amdgcn_mfma_f64_16x16x4f64(u.y, xre[jt][ks], tim, 0, 0, 0);
+                        }
+                    // X_it = p (conj applied) Tn:  re = px tr + py ti,  im = px ti - py tr
+                    const v4d ntre = -tre;
+                    xre[it] = (v4d){0.0, 0.0, 0.0, 0.0};
+                    xim[it] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const cplx pw = OP[(it * 4 + ks) * 64 + lane];
+                        xre[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(pw.x, tre[ks], xre[it], 0, 0, 0);
+                        xim[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(pw.x, tim[ks], xim[it], 0, 0, 0);
+                        xre[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(pw.y, tim[ks], xre[it], 0, 0, 0);
+                        xim[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(pw.y, ntre[ks], xim[it], 0, 0, 0);
+                    }
+                    nxim[it] = -xim[it];
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int rl = 16 * it + lk + 4 * reg, col = c0 + 16 * b + li;
+                        if (rl < nb && col < D)
+                            Z[(int64_t)(j0 + rl) * D + col] = c_make(xre[it][reg], xim[it][reg]);
+                    }
+                }
             }
             __syncthreads();
         }
     }
 }
 
-__global__ __launch_bounds__(256) void chol_backsolve_kernel(const cplx *__restrict__ R,
+// (3 waves per SIMD asked for explicitly: 513 = 2 * 256 + 1 workgroups need 3 resident per
+// CU to run in one round, and the allocator otherwise stops one register above the limit)
+__global__ __launch_bounds__(256, 3) void chol_backsolve_kernel(const cplx *__restrict__ R,
                                                              cplx *__restrict__ P, int n, int D) {
     __shared__ cplx S[CH_NB * BS_LD];
+    __shared__ cplx OP[BS_OPS];
     const int f = blockIdx.x;
-    chol_backsolve_body(R + (int64_t)f * n * n, P + (int64_t)f * n * D, n, D, S);
+    chol_backsolve_body(R + (int64_t)f * n * n, P + (int64_t)f * n * D, n, D, S, OP);
 }
 
 // ------------------------------------------------------------------ apply
@@ -1234,7 +1309,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         ctx->wpe_tiles_key[2] != D || ctx->wpe_tiles_key[3] != corr_ts) {
         GSS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (!ctx->wpe_tiles)
-            GSS_HIP_CHECK(ctx, hipMalloc(&ctx->wpe_tiles, sizeof(CorrTile) * (1024 + 4096)));
+            GSS_HIP_CHECK(ctx, hipMalloc(&ctx->wpe_tiles, sizeof(CorrTile) * (1024 + 4096 + 1)));
         GSS_HIP_CHECK(ctx, hipMemcpy(ctx->wpe_tiles, tiles.data(), sizeof(CorrTile) * ntiles,
                                      hipMemcpyHostToDevice));
         if (!upd.empty())
@@ -1248,6 +1323,10 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     }
     CorrTile *tiles_dev = reinterpret_cast<CorrTile *>(ctx->wpe_tiles);
     UpdTile *upd_dev = reinterpret_cast<UpdTile *>(tiles_dev + 1024);
+    // zeroed pivots of this call (all iterations, all frequencies): counted on the device,
+    // copied to the context's status words at the end (gss_last_wpe_zero_pivots)
+    int32_t *zero_pivots = reinterpret_cast<int32_t *>(tiles_dev + 1024 + 4096);
+    GSS_HIP_CHECK(ctx, hipMemsetAsync(zero_pivots, 0, sizeof(int32_t), ctx->stream));
 
     const int padf = corr_padf(D, 16 * corr_ts);
     // 3 real MFMAs per complex product (t1 = ar br, t2 = ai bi, t3 = (ar + ai)(br - bi));
@@ -1372,7 +1451,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                 {
                     GSS_PROF(ctx, "wpe_chol_diag");
                     hipLaunchKernelGGL(chol_diag_kernel, dim3(F), dim3(256), panel_lds, ctx->stream, R, n,
-                                       j0);
+                                       j0, zero_pivots);
                     GSS_LAUNCH_CHECK(ctx, "chol_diag_kernel");
                 }
                 {
@@ -1413,6 +1492,8 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
             GSS_LAUNCH_CHECK(ctx, "wpe_apply_kernel");
         }
     }
+    GSS_HIP_CHECK(ctx, hipMemcpyAsync(ctx->status_host + 2, zero_pivots, sizeof(int32_t),
+                                      hipMemcpyDeviceToHost, ctx->stream));
     return GSS_OK;
 }
 

@@ -438,14 +438,22 @@ def test_config2_end_to_end_vs_oracle(gpu_ctx, config2_run, oracle_pool):
     itself is not reproducible to that level there: the tolerance of a bin is
     max(1e-4, 100 x the oracle's last-bit sensitivity in that bin), the bins that need the
     second term must stay below 3 %, and no bin may be off by more than 1e-2.  The
-    well-conditioned variant below has no such bins."""
+    well-conditioned variant below has no such bins.
+
+    Round 3 (WPE panels by 16-blocked triangular substitution instead of the explicit
+    48 x 48 inverse): 1 of 513 bins above 1e-4 (bin 169: 2.9e-4 at an oracle
+    self-sensitivity of 8e-5), so the second term is now 10 x, at most 2 bins may need it,
+    and the global figure is held to 3e-5."""
     u, x_hat, det = config2_run
     kw = dict(return_details=True, gss_fn=oracle_pool.gss_block, wpe_fn=oracle_pool.wpe_block)
     want, wdet = oracle.enhance_observation(u.obs, u.activity_array, u.target_index, u.ex, **kw)
     assert rel_err(det['Obs'], wdet['Obs']) < 1e-6
     assert det['ref_channel'] == wdet['ref_channel']
-    assert rel_err(np.abs(det['X_hat']), np.abs(wdet['X_hat'])) < TOL_STFT_MAG
-    assert rel_err(x_hat, want) < TOL_STFT_MAG
+    glob = rel_err(np.abs(det['X_hat']), np.abs(wdet['X_hat']))
+    print('config 2 global |X_hat| error %.2e, x_hat %.2e, after WPE %.2e'
+          % (glob, rel_err(x_hat, want), rel_err(det['Obs'], wdet['Obs'])))
+    assert glob < 3e-5
+    assert rel_err(x_hat, want) < 3e-5
     # the oracle against itself, observation perturbed in the last bit
     rng = np.random.default_rng(0)
     obs2 = u.obs * (1 + 2e-16 * rng.standard_normal(u.obs.shape))
@@ -455,7 +463,7 @@ def test_config2_end_to_end_vs_oracle(gpu_ctx, config2_run, oracle_pool):
     loud = nb ** 2 > np.max(nb ** 2) * 1e-8                    # within 80 dB of the loudest bin
     err = np.linalg.norm(A - B, axis=0) / nb
     self_f = np.linalg.norm(B2 - B, axis=0) / nb
-    tol = np.maximum(TOL_STFT_MAG, 100.0 * self_f)
+    tol = np.maximum(TOL_STFT_MAG, 10.0 * self_f)
     relaxed = loud & (err >= TOL_STFT_MAG)                     # bins that need the second term
     print('config 2 per-bin |X_hat| error: median %.2e, max %.2e (bin %d, oracle self-sensitivity '
           '%.2e there); %d of %d bins above 1e-4; oracle sensitivity above 1e-6 in %d bins'
@@ -464,7 +472,14 @@ def test_config2_end_to_end_vs_oracle(gpu_ctx, config2_run, oracle_pool):
              int(loud.sum()), int((loud & (self_f > 1e-6)).sum())))
     assert loud.all()
     assert np.all(err[loud] < tol[loud]), np.flatnonzero(loud & (err >= tol))
-    assert relaxed.mean() < 0.03 and err[loud].max() < 1e-2
+    assert relaxed.sum() <= 2 and err[loud].max() < 1e-3
+    # the WPE stage itself, per bin: GPU vs oracle against the oracle's own last-bit noise
+    wpe_err = np.linalg.norm(det['Obs'] - wdet['Obs'], axis=(0, 1))
+    wpe_self = np.linalg.norm(wdet2['Obs'] - wdet['Obs'], axis=(0, 1))
+    ratio = wpe_err / np.maximum(wpe_self, 1e-300)
+    print('WPE output, GPU - oracle over oracle self-noise per bin: median %.2f, max %.2f (bin %d)'
+          % (np.median(ratio), ratio.max(), int(np.argmax(ratio))))
+    assert np.median(ratio) < 2.0
 
 
 def test_config2_well_conditioned_all_bins_per_frequency(gpu_ctx, oracle_pool):
