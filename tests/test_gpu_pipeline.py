@@ -479,7 +479,10 @@ def test_config2_end_to_end_vs_oracle(gpu_ctx, config2_run, oracle_pool):
     ratio = wpe_err / np.maximum(wpe_self, 1e-300)
     print('WPE output, GPU - oracle over oracle self-noise per bin: median %.2f, max %.2f (bin %d)'
           % (np.median(ratio), ratio.max(), int(np.argmax(ratio))))
-    assert np.median(ratio) < 2.0
+    # (measured: median 1.98, max 2.66 -- the correlation matrix is summed frame by frame on
+    # the MFMA, BLAS sums in blocks; test_wpe_config2_bins_within_oracle_noise_... has the
+    # same factor against the extended-precision solution)
+    assert np.median(ratio) < 3.0 and ratio.max() < 5.0
 
 
 def test_config2_well_conditioned_all_bins_per_frequency(gpu_ctx, oracle_pool):
