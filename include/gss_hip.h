@@ -60,7 +60,7 @@ typedef enum {
 
 /* Limits of the built kernels. */
 #define GSS_MAX_CHANNELS 32    /* reference asserts D < 30 (beamforming_wrapper.py:44) */
-#define GSS_MAX_CLASSES 8      /* pb_bss asserts K < 20; CHiME-5/6 use K <= 5           */
+#define GSS_MAX_CLASSES 19     /* pb_bss asserts K < 20 (CACGMMTrainer.fit); CHiME-5/6: K <= 5 */
 #define GSS_MAX_STFT_SIZE 4096
 
 /* ABI revision of this header.  Bumped whenever an entry point changes its argument list

@@ -18,6 +18,7 @@
 //    B_k,de = sum_t w_kt P_de(t)
 // where Mq holds B_k^-1 with the off-diagonals doubled.  That is 4 real FMAs per
 // (entry, class, frame) instead of 12 for the dense form.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -115,7 +116,10 @@ __global__ __launch_bounds__(256) void em_estep_kernel(EmArgs a, const cplx *__r
         ldet[tid] = a.logdet[f * K + tid];
         pis[tid] = a.pi[f * K + tid];
     }
-    double sg[2] = {0.0, 0.0};   // sum of gamma for classes g and g + 4
+    constexpr int NS = (K + 3) / 4;   // classes per wave in the softmax: g, g + 4, ...
+    double sg[NS];               // sums of gamma for those classes
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sg[s] = 0.0;
 
     for (int64_t t0 = c0; t0 < c1; t0 += EM_TILE) {
         const int64_t t = t0 + tl;
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void em_estep_kernel(EmArgs a, const cplx *__r
             for (int k = 0; k < K; ++k)
                 ssum += (valid && a.act[(int64_t)k * a.act_stride + t]) ? 1.0 : 1e-10;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < NS; ++s) {
                 const int k = g + 4 * s;
                 if (k < K && valid) {
                     const double v = a.act[(int64_t)k * a.act_stride + t] ? 1.0 : 1e-10;
@@ -178,10 +182,12 @@ __global__ __launch_bounds__(256) void em_estep_kernel(EmArgs a, const cplx *__r
 #pragma unroll
         for (int k = 0; k < K; ++k) qpart[(g * K + k) * EM_TILE + tl] = q[k];
         __syncthreads();
-        // ---- log-likelihoods: thread (tl, g) handles classes g and g + 4
-        double myq[2] = {1.0, 1.0};
+        // ---- log-likelihoods: thread (tl, g) handles classes g, g + 4, ...
+        double myq[NS];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NS; ++s) myq[s] = 1.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
             const int k = g + 4 * s;
             if (k < K) {
                 double qv = qpart[k * EM_TILE + tl] + qpart[(K + k) * EM_TILE + tl] +
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void em_estep_kernel(EmArgs a, const cplx *__r
 #pragma unroll
         for (int k = 0; k < K; ++k) mx = fmax(mx, lpS[k * EM_TILE + tl]);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NS; ++s) {
             const int k = g + 4 * s;
             if (k < K) {
                 double v = exp(lpS[k * EM_TILE + tl] - mx) * pis[k];
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(256) void em_estep_kernel(EmArgs a, const cplx *__r
         for (int k = 0; k < K; ++k) ssum += vvS[k * EM_TILE + tl];
         ssum = fmax(ssum, GSS_TINY);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NS; ++s) {
             const int k = g + 4 * s;
             if (k < K && valid) {
                 double gam = vvS[k * EM_TILE + tl] / ssum;
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(256) void em_estep_kernel(EmArgs a, const cplx *__r
     }
     if (MODE == MODE_PREDICT) return;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < NS; ++s) {
         const int k = g + 4 * s;
         const double tot = wave_sum(sg[s]);
         if (k < K && tl == 0) a.Sg[((int64_t)f * a.nch + chunk) * K + k] = tot;
@@ -381,11 +387,14 @@ __host__ __device__ inline WcovLds wcov_lds_layout(int D, int KW) {
     return L;
 }
 
+// KW weight rows per launch out of the Ktot rows of W / part, starting at row k0 (the
+// M-step of more than 8 classes runs in groups).
 template <int KW, bool NORMALISE, bool SRC_FDT, bool PREFETCH = false>
 __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
                                                    const double *__restrict__ W, int F,
                                                    int64_t T, int D, int NE, int nch,
-                                                   int chunk_frames, cplx *__restrict__ part) {
+                                                   int chunk_frames, cplx *__restrict__ part,
+                                                   int Ktot, int k0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WcovLds L = wcov_lds_layout(D, KW);
     const int Dp = L.Dp;
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
     const int64_t c0 = (int64_t)chunk * chunk_frames;
     const int64_t c1 = c0 + chunk_frames < T ? c0 + chunk_frames : T;
     const cplx *Yf = Y + (int64_t)f * T * D;
-    const double *Wf = W + (int64_t)f * KW * T;
+    const double *Wf = W + ((int64_t)f * Ktot + k0) * T;
 
     {
         const int nb2 = Dp / 2;
@@ -522,7 +531,7 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
         }
     }
     if (fg == 0) {
-        cplx *pp = part + ((int64_t)f * nch + chunk) * KW * NE;
+        cplx *pp = part + (((int64_t)f * nch + chunk) * Ktot + k0) * NE;
         const int bi = blk[2 * mb], bj = blk[2 * mb + 1];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -1007,12 +1016,12 @@ int launch_estep_reg_k(gss_ctx *ctx, int K, int mode, const EmArgs &a, const cpl
     return gss_fail(ctx, GSS_ERR_UNSUPPORTED, "cacgmm: K=%d", K);
 }
 
-template <int K>
-int launch_mstep(gss_ctx *ctx, const EmArgs &a, const cplx *Yn, int F) {
-    const size_t lds = wcov_lds_layout(a.D, K).total;
+template <int KW>
+int launch_mstep(gss_ctx *ctx, const EmArgs &a, const cplx *Yn, int F, int K, int k0) {
+    const size_t lds = wcov_lds_layout(a.D, KW).total;
     GSS_PROF(ctx, "em_mstep");
-    if (Yn && a.D == 4 && K >= 2 && K <= 6 && getenv("GSS_MSTEP_TILED") == nullptr) {
-        hipLaunchKernelGGL((mstep_reg_kernel<(K >= 2 && K <= 6 ? K : 2), 4>),
+    if (Yn && a.D == 4 && KW == K && K >= 2 && K <= 6 && getenv("GSS_MSTEP_TILED") == nullptr) {
+        hipLaunchKernelGGL((mstep_reg_kernel<(KW >= 2 && KW <= 6 ? KW : 2), 4>),
                            dim3(xcd_grid(a.nch, F)), dim3(64), 0, ctx->stream, Yn, a.W, F, a.T,
                            a.nch, a.chunk_frames, a.Bp);
         GSS_LAUNCH_CHECK(ctx, "mstep_reg_kernel");
@@ -1024,46 +1033,61 @@ int launch_mstep(gss_ctx *ctx, const EmArgs &a, const cplx *Yn, int F) {
         // 0.130 / 0.118)
         static const int pf_max_d = getenv("GSS_MSTEP_PREFETCH_D") ? atoi(getenv("GSS_MSTEP_PREFETCH_D")) : 12;
         if (a.D <= pf_max_d) {
-            GSS_TRY(raise_lds_limit(ctx, wcov_kernel<K, false, true, true>, lds));
-            hipLaunchKernelGGL((wcov_kernel<K, false, true, true>), dim3(xcd_grid(a.nch, F)),
+            GSS_TRY(raise_lds_limit(ctx, wcov_kernel<KW, false, true, true>, lds));
+            hipLaunchKernelGGL((wcov_kernel<KW, false, true, true>), dim3(xcd_grid(a.nch, F)),
                                dim3(256), lds, ctx->stream, Yn, a.W, F, a.T, a.D, a.NE, a.nch,
-                               a.chunk_frames, a.Bp);
+                               a.chunk_frames, a.Bp, K, k0);
         } else {
-            GSS_TRY(raise_lds_limit(ctx, wcov_kernel<K, false, true>, lds));
-            hipLaunchKernelGGL((wcov_kernel<K, false, true>), dim3(xcd_grid(a.nch, F)), dim3(256),
+            GSS_TRY(raise_lds_limit(ctx, wcov_kernel<KW, false, true>, lds));
+            hipLaunchKernelGGL((wcov_kernel<KW, false, true>), dim3(xcd_grid(a.nch, F)), dim3(256),
                                lds, ctx->stream, Yn, a.W, F, a.T, a.D, a.NE, a.nch, a.chunk_frames,
-                               a.Bp);
+                               a.Bp, K, k0);
         }
         GSS_LAUNCH_CHECK(ctx, "wcov_kernel");
         return GSS_OK;
     }
-    GSS_TRY(raise_lds_limit(ctx, wcov_kernel<K, true, false>, lds));
-    hipLaunchKernelGGL((wcov_kernel<K, true, false>), dim3(xcd_grid(a.nch, F)), dim3(256), lds,
-                       ctx->stream, a.Y, a.W, F, a.T, a.D, a.NE, a.nch, a.chunk_frames, a.Bp);
+    GSS_TRY(raise_lds_limit(ctx, wcov_kernel<KW, true, false>, lds));
+    hipLaunchKernelGGL((wcov_kernel<KW, true, false>), dim3(xcd_grid(a.nch, F)), dim3(256), lds,
+                       ctx->stream, a.Y, a.W, F, a.T, a.D, a.NE, a.nch, a.chunk_frames, a.Bp, K, k0);
     GSS_LAUNCH_CHECK(ctx, "wcov_kernel");
     return GSS_OK;
 }
 
-#define GSS_K_SWITCH(K, CALL)                                              \
+#define GSS_K_CASE(N, CALL) case N: { constexpr int KK = N; return CALL; }
+#define GSS_K_SWITCH8(K, CALL)                                             \
     switch (K) {                                                           \
-        case 1: { constexpr int KK = 1; return CALL; }                     \
-        case 2: { constexpr int KK = 2; return CALL; }                     \
-        case 3: { constexpr int KK = 3; return CALL; }                     \
-        case 4: { constexpr int KK = 4; return CALL; }                     \
-        case 5: { constexpr int KK = 5; return CALL; }                     \
-        case 6: { constexpr int KK = 6; return CALL; }                     \
-        case 7: { constexpr int KK = 7; return CALL; }                     \
-        case 8: { constexpr int KK = 8; return CALL; }                     \
+        GSS_K_CASE(1, CALL) GSS_K_CASE(2, CALL) GSS_K_CASE(3, CALL) GSS_K_CASE(4, CALL)     \
+        GSS_K_CASE(5, CALL) GSS_K_CASE(6, CALL) GSS_K_CASE(7, CALL) GSS_K_CASE(8, CALL)     \
+    }
+// pb_bss: assert K < 20 (CACGMMTrainer.fit)
+#define GSS_K_SWITCH19(K, CALL)                                            \
+    switch (K) {                                                           \
+        GSS_K_CASE(1, CALL) GSS_K_CASE(2, CALL) GSS_K_CASE(3, CALL) GSS_K_CASE(4, CALL)     \
+        GSS_K_CASE(5, CALL) GSS_K_CASE(6, CALL) GSS_K_CASE(7, CALL) GSS_K_CASE(8, CALL)     \
+        GSS_K_CASE(9, CALL) GSS_K_CASE(10, CALL) GSS_K_CASE(11, CALL) GSS_K_CASE(12, CALL) \
+        GSS_K_CASE(13, CALL) GSS_K_CASE(14, CALL) GSS_K_CASE(15, CALL) GSS_K_CASE(16, CALL) \
+        GSS_K_CASE(17, CALL) GSS_K_CASE(18, CALL) GSS_K_CASE(19, CALL)                     \
     }
 
 int launch_estep_k(gss_ctx *ctx, int K, int mode, const EmArgs &a, const cplx *Mq, int F) {
-    GSS_K_SWITCH(K, launch_estep<KK>(ctx, mode, a, Mq, F));
+    GSS_K_SWITCH19(K, launch_estep<KK>(ctx, mode, a, Mq, F));
     return gss_fail(ctx, GSS_ERR_UNSUPPORTED, "cacgmm: K=%d", K);
 }
 
+int launch_mstep_group(gss_ctx *ctx, int KW, const EmArgs &a, const cplx *Yn, int F, int K,
+                       int k0) {
+    GSS_K_SWITCH8(KW, launch_mstep<KK>(ctx, a, Yn, F, K, k0));
+    return gss_fail(ctx, GSS_ERR_UNSUPPORTED, "cacgmm: class group of %d", KW);
+}
+
+// The M-step keeps 4 complex accumulators per class and thread: up to 8 classes per launch;
+// more classes (pb_bss allows K < 20: RTTM sessions with many speakers) go in groups of
+// equal size, each a pass over the observation.
 int launch_mstep_k(gss_ctx *ctx, int K, const EmArgs &a, const cplx *Yn, int F) {
-    GSS_K_SWITCH(K, launch_mstep<KK>(ctx, a, Yn, F));
-    return gss_fail(ctx, GSS_ERR_UNSUPPORTED, "cacgmm: K=%d", K);
+    const int ngroups = (K + 7) / 8, per = (K + ngroups - 1) / ngroups;
+    for (int k0 = 0; k0 < K; k0 += per)
+        GSS_TRY(launch_mstep_group(ctx, std::min(per, K - k0), a, Yn, F, K, k0));
+    return GSS_OK;
 }
 
 }  // namespace
@@ -1075,7 +1099,7 @@ int psd_partials_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const
     const size_t lds = wcov_lds_layout(D, 2).total;
     GSS_TRY(raise_lds_limit(ctx, wcov_kernel<2, false, false>, lds));
     hipLaunchKernelGGL((wcov_kernel<2, false, false>), dim3(xcd_grid(nch, F)), dim3(256), lds,
-                       ctx->stream, Y, W2, F, T, D, tri_count(D), nch, chunk_frames, part);
+                       ctx->stream, Y, W2, F, T, D, tri_count(D), nch, chunk_frames, part, 2, 0);
     GSS_LAUNCH_CHECK(ctx, "wcov_kernel");
     return GSS_OK;
 }
@@ -1154,7 +1178,8 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
         return launch_estep_k(ctx, K, mode, a, Mq, F);
     };
 
-    GSS_REQUIRE(ctx, em_estep_lds(D, K) <= 160 * 1024 && wcov_lds_layout(D, K).total <= 160 * 1024,
+    GSS_REQUIRE(ctx, em_estep_lds(D, K) <= 160 * 1024 &&
+                         wcov_lds_layout(D, std::min(K, 8)).total <= 160 * 1024,
                 GSS_ERR_UNSUPPORTED, "cacgmm: D=%d K=%d LDS", D, K);
     const int m = D + (D & 1);
     const size_t eigh_lds = (sizeof(cplx) * 2 * m * m + sizeof(double) * m + 15) / 16 * 16;

@@ -390,8 +390,9 @@ extern "C" int gss_wpe(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T, int D,
 static int check_cacgmm_args(gss_ctx *ctx, int D, int K, int iterations, int post) {
     GSS_REQUIRE(ctx, D >= 2 && D <= GSS_MAX_CHANNELS, GSS_ERR_UNSUPPORTED,
                 "cacgmm: D=%d outside [2, %d]", D, GSS_MAX_CHANNELS);
-    GSS_REQUIRE(ctx, K >= 1 && K <= GSS_MAX_CLASSES, GSS_ERR_UNSUPPORTED,
-                "cacgmm: K=%d outside [1, %d]", K, GSS_MAX_CLASSES);
+    // pb_bss CACGMMTrainer.fit: assert K < 20 (-> AssertionError in the reference too)
+    GSS_REQUIRE(ctx, K >= 1 && K <= GSS_MAX_CLASSES, GSS_ERR_INVALID,
+                "cacgmm: assert 1 <= K < 20 failed: K=%d", K);
     GSS_REQUIRE(ctx, iterations >= 1 && post >= 0, GSS_ERR_INVALID,
                 "cacgmm: iterations=%d iterations_post=%d", iterations, post);
     return GSS_OK;

@@ -289,7 +289,9 @@ def _scene(rng, D, T, F, K):
 @pytest.mark.parametrize('D,T,F,K,iters,post', [
     (4, 100, 6, 3, 5, 1), (4, 100, 6, 3, 3, 0), (4, 100, 6, 3, 2, 3), (2, 64, 3, 2, 4, 1),
     (7, 200, 4, 4, 6, 1), (24, 400, 3, 5, 10, 1), (12, 333, 3, 5, 8, 1), (5, 65, 2, 1, 3, 1),
-    (29, 150, 2, 3, 3, 1), (6, 129, 3, 8, 4, 1)])
+    (29, 150, 2, 3, 3, 1), (6, 129, 3, 8, 4, 1),
+    # more than 8 classes (pb_bss allows K < 20): the M-step runs in class groups
+    (8, 300, 3, 9, 4, 1), (24, 260, 2, 12, 3, 1), (12, 400, 2, 19, 3, 0), (4, 500, 3, 19, 3, 2)])
 def test_cacgmm_matches_oracle(gpu_ctx, D, T, F, K, iters, post):
     from pb_chime5_amd import ops
     rng = np.random.default_rng(D + T + K)

@@ -131,6 +131,40 @@ def test_enhance_session_end_to_end_vs_oracle(gpu_ctx, tmp_path):
     assert np.max(np.abs(pcm - ref)) <= 1.01 / 2 ** 15
 
 
+@pytest.mark.gpu
+def test_rttm_with_nine_speakers_runs_like_the_reference(gpu_ctx, tmp_path):
+    """A diarisation RTTM with 9 speakers -> K = 10 classes with the garbage class
+    (core_chime6_rttm.py:36-69 builds one activity row per RTTM speaker; pb_bss accepts
+    K < 20).  Rounds 1-2 stopped at 8 classes."""
+    import gss_oracle as oracle
+    from pb_chime5_amd.core_chime6_rttm import get_enhancer
+    root, rttm_file, _ = _make_chime6_dir(tmp_path)
+    lines = []
+    for k in range(9):
+        lines.append(f'SPEAKER S02_U06.ENH 1 {0.25 * k:.2f} {0.75 + 0.125 * (k % 3):.3f} <NA> <NA> '
+                     f'spk{k} <NA>\n')
+    rttm_file.write_text(''.join(lines))
+    enh = get_enhancer(database_rttm=[str(rttm_file)], activity_rttm=[str(rttm_file)],
+                       chime6_dir=root, multiarray='outer_array_mics', context_samples=8000,
+                       wpe_tabs=2, bss_iterations=3)
+    ds = enh.get_dataset('S02')
+    assert len(ds) == 9
+    ex = ds[4]
+    act = {k: v[ex['start']:ex['end']] for k, v in enh.activity['S02'].items()}
+    assert len(act) == 10 and list(act)[-1] == 'Noise'
+    target = list(act).index(ex['speaker_id'])
+    oex = {'start': {'original': ex['start']}, 'start_orig': {'original': ex['start_orig']},
+           'end_orig': {'original': ex['end_orig']}, 'end': {'original': ex['end']}}
+    want = oracle.enhance_observation(ex['audio_data'], np.array(list(act.values())), target, oex,
+                                      wpe_taps=2, bss_iterations=3,
+                                      gss_fn=oracle.gss_block_batched)
+    lo = ex['start_orig'] - ex['start']
+    want = want[lo:lo + ex['num_samples_orig']]
+    got = enh.enhance_example(ex)
+    assert got.shape == want.shape
+    assert rel_err(got, want) < 1e-5
+
+
 # ---------------------------------------------------------------- reference fixture
 GOLDEN = __import__('pathlib').Path(__file__).parent / 'golden'
 
