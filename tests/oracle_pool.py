@@ -15,8 +15,13 @@ REPO = Path(__file__).resolve().parent.parent
 
 
 def _init():
-    for var in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):
-        os.environ[var] = '1'
+    # one BLAS thread per worker, like the reference's own processes
+    # (pb_chime5/__init__.py:3-14).  NumPy is already imported when this runs (unpickling
+    # this function imports the module), so the limit is set at run time, not through the
+    # environment -- which would leak into everything the test process starts later.
+    import threadpoolctl
+    global _LIMIT
+    _LIMIT = threadpoolctl.threadpool_limits(1)
     for p in (str(REPO), str(REPO / 'oracle')):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -52,10 +57,6 @@ class OraclePool:
     def __init__(self, workers=None, bins_per_job=12):
         self.workers = workers or max(1, min(14, usable_cpus() - 2))
         self.bins_per_job = bins_per_job
-        # the workers inherit the environment: pin their numeric libraries to one thread
-        # BEFORE they import NumPy (the initializer below runs after the import)
-        for var in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):
-            os.environ[var] = '1'
         self._ex = ProcessPoolExecutor(self.workers, mp_context=mp.get_context('spawn'),
                                        initializer=_init)
 
