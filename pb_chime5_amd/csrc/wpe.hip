@@ -69,14 +69,39 @@ __global__ __launch_bounds__(POW_FRAMES) void wpe_power_kernel(const cplx *__res
     if (psd_context > 0) {
         __syncthreads();      // the raw powers of this frequency are complete (same workgroup)
         mx = 0.0;
-        for (int64_t t = tid; t < T; t += POW_FRAMES) {
-            const int64_t lo = t - psd_context > 0 ? t - psd_context : 0;
-            const int64_t hi = t + psd_context < T - 1 ? t + psd_context : T - 1;
+        if (psd_context <= 16) {
+            // short windows: the plain sum, in np.correlate's order
+            for (int64_t t = tid; t < T; t += POW_FRAMES) {
+                const int64_t lo = t - psd_context > 0 ? t - psd_context : 0;
+                const int64_t hi = t + psd_context < T - 1 ? t + psd_context : T - 1;
+                double sum = 0.0;
+                for (int64_t u = lo; u <= hi; ++u) sum += wf[u];
+                const double p = sum / (double)(hi - lo + 1);
+                wout[t] = p;
+                mx = fmax(mx, p);
+            }
+        } else {
+            // long windows: every thread takes a run of consecutive frames, sums the first
+            // window and slides it (O(T / 256 + p) per thread instead of O(T p / 256))
+            const int64_t run = (T + POW_FRAMES - 1) / POW_FRAMES;
+            const int64_t t_beg = (int64_t)tid * run, t_end = t_beg + run < T ? t_beg + run : T;
             double sum = 0.0;
-            for (int64_t u = lo; u <= hi; ++u) sum += wf[u];
-            const double p = sum / (double)(hi - lo + 1);
-            wout[t] = p;
-            mx = fmax(mx, p);
+            int64_t lo = 0, hi = -1;
+            for (int64_t t = t_beg; t < t_end; ++t) {
+                const int64_t nlo = t - psd_context > 0 ? t - psd_context : 0;
+                const int64_t nhi = t + psd_context < T - 1 ? t + psd_context : T - 1;
+                if (t == t_beg) {
+                    for (int64_t u = nlo; u <= nhi; ++u) sum += wf[u];
+                } else {
+                    if (nhi > hi) sum += wf[nhi];
+                    if (nlo > lo) sum -= wf[lo];
+                }
+                lo = nlo;
+                hi = nhi;
+                const double p = sum / (double)(hi - lo + 1);
+                wout[t] = p;
+                mx = fmax(mx, p);
+            }
         }
     }
     mx = wave_max(mx);
@@ -1256,10 +1281,11 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     }
     GSS_REQUIRE(ctx, X != Y, GSS_ERR_INVALID, "gss_wpe: X must not alias Y");
     double *w = arena_alloc_t<double>(ctx, (size_t)F * T);
-    double *raw = psd_context > 0 ? arena_alloc_t<double>(ctx, (size_t)F * T) : w;
+    // (NULL without smoothing: the kernel's two __restrict__ outputs must not alias)
+    double *raw = psd_context > 0 ? arena_alloc_t<double>(ctx, (size_t)F * T) : nullptr;
     cplx *R = arena_alloc_t<cplx>(ctx, (size_t)F * n * n);
     cplx *P = arena_alloc_t<cplx>(ctx, (size_t)F * n * D);
-    GSS_REQUIRE(ctx, w && raw && R && P, GSS_ERR_NOMEM, "wpe workspace");
+    GSS_REQUIRE(ctx, w && (raw || psd_context == 0) && R && P, GSS_ERR_NOMEM, "wpe workspace");
 
     // tile lists: correlation tiles, then one trailing-update list per block column
     std::vector<CorrTile> tiles;
@@ -1379,6 +1405,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     size_t packed_lds = 0;
     {
         const int ph_env = getenv("GSS_APPLY_PH") ? atoi(getenv("GSS_APPLY_PH")) : 0;   // tests
+        bool ph_env_taken = ph_env <= 1;
         double best = (double)((D + 15) / 16) * n;
         for (int ph = 2; ph <= 4; ++ph) {
             if (ph_env > 0 && ph != ph_env) continue;
@@ -1392,6 +1419,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
             // prologue, and it is slower: 1.82 vs 1.35 ms, 3.10 vs 2.28 ms per utterance)
             if (lds > (ph_env == ph ? 160 : 64) * 1024) continue;
             if (cost < 0.75 * best || ph_env == ph) {
+                ph_env_taken = ph_env_taken || ph_env == ph;
                 best = cost;
                 apply_ph = ph;
                 apply_nt = nt;
@@ -1399,6 +1427,13 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
             }
         }
         if (ph_env == 1 || !apply_3m) apply_ph = 1;
+        if (!ph_env_taken) {
+            static bool warned = false;      // a forced variant that does not exist for this shape
+            if (!warned)
+                fprintf(stderr, "libgss_hip: GSS_APPLY_PH=%d is not available for D=%d taps=%d "
+                                "(column tiles or LDS); using the default\n", ph_env, D, taps);
+            warned = true;
+        }
     }
     using apply_packed_t = void (*)(const cplx *, const cplx *, int, int64_t, int, int, int, cplx *);
     apply_packed_t packed_fn = nullptr;

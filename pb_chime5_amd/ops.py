@@ -141,11 +141,25 @@ def _ftd_to_host_dtf(ctx, buf, D, T, F):
     return ctx.to_host(tmp, (D, T, F), np.complex128)
 
 
+def check_psd_context(psd_context):
+    """nara_wpe.wpe.get_power accepts an int (frames either side), a (left, right) tuple and
+    np.inf (global mean); the kernels implement the symmetric integer window
+    (core.py:56,583 passes an int, default 0).  Everything else is refused in ONE place with
+    NotImplementedError -- never truncated, never a TypeError / OverflowError from int()."""
+    ok = isinstance(psd_context, (int, np.integer)) and not isinstance(psd_context, bool)
+    if not ok and isinstance(psd_context, (float, np.floating)):
+        ok = np.isfinite(psd_context) and float(psd_context).is_integer()
+    if not ok or psd_context < 0 or psd_context > 2 ** 31 - 1:
+        raise NotImplementedError(
+            f'psd_context={psd_context!r}: only a non-negative integer number of frames is '
+            'implemented (no (left, right) tuple, no np.inf)')
+    return int(psd_context)
+
+
 def wpe_dtf(Obs, taps=10, delay=2, iterations=3, psd_context=0, *, ctx=None):
     """WPE on the reference's (D,T,F) layout (what ``WPE.__call__`` hands over
     transposed to wpe_v8 and transposes back, core.py:52-58)."""
-    if isinstance(psd_context, tuple) or int(psd_context) != psd_context or psd_context < 0:
-        raise NotImplementedError(f'psd_context={psd_context!r}: a non-negative integer')
+    psd_context = check_psd_context(psd_context)
     ctx = ctx or default_context()
     Y_d, (D, T, F) = _obs_to_device_ftd(ctx, Obs)
     X_d = ctx.empty(16 * F * T * D)
@@ -199,7 +213,8 @@ def _check_ref_channel(ctx):
     """pb_bss get_optimal_reference_channel: ``assert np.all(np.isfinite(SNR)), SNR`` --
     the reference aborts the utterance; the device reports it as reference channel -1."""
     ref = ctx.last_ref_channel()
-    assert ref != -1, 'get_optimal_reference_channel: the SNR is not finite'
+    if ref == -1:       # (not an `assert` statement: those vanish under python -O)
+        raise AssertionError('get_optimal_reference_channel: the SNR is not finite')
     return ref
 
 
@@ -277,7 +292,7 @@ def make_params(*, stft_size=1024, stft_shift=256, stft_fading=True, wpe=True, w
         wpe_iterations=wpe_iterations, bss_iterations=bss_iterations,
         bss_iterations_post=bss_iterations_post, bf_drop_context=int(bool(bf_drop_context)),
         bf=_BF_CODES[bf], postfilter=_POSTFILTER_CODES[postfilter],
-        wpe_psd_context=int(wpe_psd_context))
+        wpe_psd_context=check_psd_context(wpe_psd_context))
 
 
 class ResidentUtterance:
@@ -384,20 +399,33 @@ class UtterancePipeline:
     def pop(self):
         tag, slot, n_out = self._pending.popleft()
         x_hat = self.slots[slot].to_host(self._bufs[slot]['out'], (n_out,), np.float64)
-        if self.params.bf == _BF_CODES['mvdrSouden_ban']:
-            try:
-                _check_ref_channel(self.slots[slot])
-            except AssertionError as e:
-                raise AssertionError(f'{tag}: {e}') from None
+        if self.params.bf == _BF_CODES['mvdrSouden_ban'] and self.slots[slot].last_ref_channel() == -1:
+            # pb_bss get_optimal_reference_channel: assert np.all(np.isfinite(SNR)).  Raised
+            # explicitly (an `assert` statement disappears under python -O and NaN audio would
+            # be written silently); `tag` may be a whole example dict: name it by its id.
+            name = tag.get('example_id', '?') if isinstance(tag, dict) else tag
+            raise AssertionError(f'{name}: get_optimal_reference_channel: the SNR is not finite')
         return tag, x_hat
 
     def close(self):
-        while self._pending:
-            self.pop()
-        self._bufs = [dict() for _ in self.slots]
-        for c in self.slots[1:]:
-            c.close()
-        self.slots = self.slots[:1]
+        """Drain what is still in flight WITHOUT the status check (close() runs in `finally`
+        blocks: a second exception here would mask the first one and leak the extra
+        contexts), then release buffers and contexts."""
+        try:
+            while self._pending:
+                _, slot, _ = self._pending.popleft()
+                try:
+                    self.slots[slot].synchronize()
+                except Exception:
+                    pass
+        finally:
+            self._bufs = [dict() for _ in self.slots]
+            for c in self.slots[1:]:
+                try:
+                    c.close()
+                except Exception:
+                    pass
+            self.slots = self.slots[:1]
 
 
 def enhance_observation(obs, activity, target_index, start_context_samples,

@@ -68,3 +68,15 @@ def oracle_pool():
 def gpu_ctx():
     from pb_chime5_amd._capi import default_context
     return default_context(0)
+
+
+@pytest.fixture(scope='session')
+def ref_mismatches():
+    """Every case in which the GPU picked another reference channel than the oracle (each one
+    certified as a tie or a degenerate scene and re-checked with the oracle's channel forced,
+    tests/test_gpu_pipeline.py::_check_ref_channel_or_tie).  Bounded when the session ends --
+    independent of test order, -k selections and xdist."""
+    found = []
+    yield found
+    print('reference-channel mismatches:', found)
+    assert len(found) <= 3, found

@@ -1,0 +1,110 @@
+"""Test infrastructure: the beamformer formulas of pb_bss (call sites
+/root/reference/pb_chime5/speech_enhancement/beamforming_wrapper.py:49-75) evaluated in 80-bit
+extended precision, one frequency at a time -- the referee for frequency bins where the
+float64 evaluation of those formulas (the reference's, hence the oracle's) is itself decided by
+rounding: with a nearly singular noise PSD matrix np.linalg.solve loses cond(Phi_N) * eps and
+blind_analytic_normalization's four-operand einsum cancels catastrophically once
+cond(Phi_N)^2 * eps > 1.  Same formulas, ~3 more decimal digits, own linear algebra
+(Gaussian elimination with partial pivoting below; numpy.linalg has no longdouble path)."""
+import numpy as np
+
+LD, CLD = np.longdouble, np.clongdouble
+
+
+def psd(Y, mask):
+    """get_power_spectral_density_matrix for one frequency: Y (D, T) complex128, mask (T,)
+    -> (D, D) clongdouble, normalised by max(sum mask, 1e-10)."""
+    Yl = Y.astype(CLD)
+    m = mask.astype(LD)
+    m = m / max(m.sum(), LD(1e-10))
+    return (Yl * m) @ Yl.conj().T
+
+
+def solve(A, B):
+    """A X = B by Gaussian elimination with partial pivoting, clongdouble."""
+    A = A.astype(CLD).copy()
+    B = B.astype(CLD).copy()
+    n = A.shape[0]
+    for j in range(n):
+        p = j + int(np.argmax(np.abs(A[j:, j])))
+        if p != j:
+            A[[j, p]] = A[[p, j]]
+            B[[j, p]] = B[[p, j]]
+        f = A[j + 1:, j] / A[j, j]
+        A[j + 1:] -= f[:, None] * A[j]
+        B[j + 1:] -= f[:, None] * B[j]
+    X = np.zeros_like(B)
+    for j in range(n - 1, -1, -1):
+        X[j] = (B[j] - A[j, j + 1:] @ X[j + 1:]) / A[j, j]
+    return X
+
+
+def souden_matrix(cov_x, cov_n, eps=1e-10):
+    """Phi_N^-1 Phi_X / max(trace, eps): the columns are the MVDR vectors per reference
+    channel (get_mvdr_vector_souden)."""
+    phi = solve(cov_n, cov_x)
+    return phi / max(np.trace(phi).real, LD(eps))
+
+
+def snr_terms(mat, cov_x, cov_n):
+    """Numerator and denominator of get_optimal_reference_channel's SNR for every candidate
+    channel, for one frequency (the reference sums both over the frequencies first)."""
+    num = np.real(np.einsum('dr,de,er->r', mat.conj(), cov_x, mat))
+    den = np.real(np.einsum('dr,de,er->r', mat.conj(), cov_n, mat))
+    return num, den
+
+
+def ban(w, cov_n):
+    """blind_analytic_normalization (eps = 0): w sqrt(w^H Phi_N Phi_N w) / |w^H Phi_N w|."""
+    pw = cov_n @ w
+    return w * np.sqrt(np.real(np.vdot(pw, pw))) / np.abs(np.vdot(w, pw))
+
+
+def mvdr_souden_ban_output(Y, target_mask, distortion_mask, ref_channel):
+    """X_hat (T,) of one frequency for a given reference channel, complex128."""
+    cov_x, cov_n = psd(Y, target_mask), psd(Y, distortion_mask)
+    w = ban(souden_matrix(cov_x, cov_n)[:, ref_channel], cov_n)
+    return (w.conj() @ Y.astype(CLD)).astype(np.complex128)
+
+
+def gev_ban_output(Y, target_mask, distortion_mask):
+    """beamform_gev_from_masks (beamforming_wrapper.py:77-89,192-208) for one frequency: the
+    principal generalised eigenvector of (Phi_X, Phi_N) -- float64 scipy.linalg.eigh as the
+    starting point, refined by Rayleigh quotient iteration in extended precision -- with
+    v^H Phi_N v = 1, BAN, apply.  The phase is arbitrary (compare magnitudes)."""
+    import scipy.linalg
+    cov_x, cov_n = psd(Y, target_mask), psd(Y, distortion_mask)
+    D = cov_x.shape[0]
+    try:
+        v = scipy.linalg.eigh(cov_x.astype(np.complex128), cov_n.astype(np.complex128))[1][:, -1]
+    except np.linalg.LinAlgError:           # Phi_N not positive definite in float64
+        lam, V = np.linalg.eig(np.linalg.solve(cov_n.astype(np.complex128) + 0, cov_x.astype(np.complex128)))
+        v = V[:, int(np.argmax(lam.real))]
+    v = v.astype(CLD)
+    for _ in range(4):
+        rho = np.real(np.vdot(v, cov_x @ v)) / np.real(np.vdot(v, cov_n @ v))
+        z = solve(cov_x - rho * cov_n + LD(1e-30) * np.trace(cov_x).real * np.eye(D), (cov_n @ v)[:, None])[:, 0]
+        v = z / np.sqrt(np.real(np.vdot(z, z)))
+    v = v / np.sqrt(np.real(np.vdot(v, cov_n @ v)))
+    w = ban(v, cov_n)
+    return (w.conj() @ Y.astype(CLD)).astype(np.complex128)
+
+
+def _bin_job(job):
+    Y, tm, dm, ref, bf = job
+    if bf == 'gev_ban':
+        return gev_ban_output(Y, tm, dm)
+    return mvdr_souden_ban_output(Y, tm, dm, ref)
+
+
+def beamformer_all_bins(Obs, target_mask, distortion_mask, ref_channel, bf='mvdrSouden_ban',
+                        workers=8):
+    """Obs (D, T, F), masks (T, F) -> X_hat (T, F) in extended precision, the frequencies
+    spread over worker processes."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    F = Obs.shape[-1]
+    jobs = [(np.ascontiguousarray(Obs[..., f]), np.ascontiguousarray(target_mask[:, f]),
+             np.ascontiguousarray(distortion_mask[:, f]), ref_channel, bf) for f in range(F)]
+    with ProcessPoolExecutor(workers, mp_context=mp.get_context('spawn')) as ex:
+        return np.array(list(ex.map(_bin_job, jobs, chunksize=8))).T

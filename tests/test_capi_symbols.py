@@ -63,3 +63,26 @@ def test_product_does_not_import_oracle():
                 names = [node.module or '']
             for n in names:
                 assert 'oracle' not in n, (path, n)
+
+
+def test_psd_context_is_validated_in_one_place():
+    """nara_wpe accepts an int, a (left, right) tuple and np.inf; only the symmetric integer
+    window is implemented -- everything else is NotImplementedError (never a silent
+    truncation, never TypeError / OverflowError out of int())."""
+    import numpy as np
+    from pb_chime5_amd import ops
+    assert ops.check_psd_context(0) == 0 and ops.check_psd_context(np.int64(3)) == 3
+    assert ops.check_psd_context(2.0) == 2
+    for bad in (np.inf, float('nan'), 1.5, (1, 2), -1, None, 'a', True):
+        with pytest.raises(NotImplementedError):
+            ops.check_psd_context(bad)
+    with pytest.raises(NotImplementedError):
+        ops.make_params(wpe_psd_context=np.inf)
+
+
+def test_abi_revision_is_checked_on_load(tmp_path):
+    from pb_chime5_amd import _capi
+    lib = _capi.load_library()
+    assert lib.gss_abi_version() == _capi.GSS_ABI_VERSION
+    text = (REPO / 'include' / 'gss_hip.h').read_text()
+    assert f'#define GSS_ABI_VERSION {_capi.GSS_ABI_VERSION}' in text

@@ -255,9 +255,10 @@ def test_config2_stagewise_vs_oracle_on_frequency_subset(gpu_ctx, config2_run):
     assert rel_err(x_hat, oracle.istft(det['X_hat'])) < 1e-11
 
 
-def _stagewise(gpu_ctx, u, bins, *, bf='mvdrSouden_ban', bss_iterations=20, tol_wpe=1e-6):
-    """GPU pipeline on utterance u, every stage checked against the oracle fed with the GPU's
-    own upstream tensors (WPE and EM on the frequency subset `bins`, the rest on all bins)."""
+def _scene_all_bins(gpu_ctx, pool, u, *, bf='mvdrSouden_ban', bss_iterations=20):
+    """A SURVEY 8d scene at full size, ALL 513 bins, no bin left out: dereverberated tensor
+    and posteriors against the oracle run end to end (its WPE and EM spread over worker
+    processes), the beamformer stage through _beamformer_all_bins_with_referee."""
     from pb_chime5_amd import ops
     cs = u.ex['start_orig']['original']
     ce = u.ex['end']['original'] - u.ex['end_orig']['original']
@@ -266,80 +267,118 @@ def _stagewise(gpu_ctx, u, bins, *, bf='mvdrSouden_ban', bss_iterations=20, tol_
                                          bss_iterations=bss_iterations)
     D, T = u.obs.shape[0], det['Obs'].shape[1]
     assert det['Obs'].shape == (D, T, 513)
-    Y = oracle.stft(u.obs)[..., bins]
-    assert rel_err(det['Obs'][..., bins], oracle.wpe_block(Y, 10, 2, 3)) < tol_wpe
-    act_f = oracle.activity_time_to_frequency(u.activity_array, 1024, 256, True)
-    assert np.array_equal(det['acitivity_freq'], act_f[:, :T])
-    post_want = oracle.gss_block(det['Obs'][..., bins], act_f[:, :T], bss_iterations, 1)
-    assert np.max(np.abs(det['posterior'][..., bins] - post_want)) < 1e-5
+    _, wdet = oracle.enhance_observation(
+        u.obs, u.activity_array, u.target_index, u.ex, return_details=True, bf=bf,
+        bss_iterations=bss_iterations, gss_fn=pool.gss_block, wpe_fn=pool.wpe_block)
+    assert np.array_equal(det['acitivity_freq'], wdet['activity_freq'][:, :T])
+    nrm = np.linalg.norm(wdet['Obs'], axis=(0, 1))
+    wpe_err = np.linalg.norm(det['Obs'] - wdet['Obs'], axis=(0, 1)) / nrm
+    post_err = np.max(np.abs(det['posterior'] - np.where(wdet['masks'] == 0, det['posterior'],
+                                                         wdet['masks'])), axis=(0, 1))
+    print('all bins: after WPE per-bin error max %.2e (bin %d) median %.2e; posteriors max %.2e '
+          '(bin %d) median %.2e' % (wpe_err.max(), int(np.argmax(wpe_err)), np.median(wpe_err),
+                                    post_err.max(), int(np.argmax(post_err)), np.median(post_err)))
+    assert wpe_err.max() < 1e-6
+    assert post_err.max() < 1e-4
     masks = det['posterior'].copy()
     sf, ef = oracle.start_end_context_frames(u.ex, 1024, 256, True)
     masks[:, :sf] = 0
     if ef > 0:
         masks[:, -ef:] = 0
-    tm = masks[u.target_index]
-    dm = np.sum(np.delete(masks, u.target_index, axis=0), axis=0)
-    assert np.array_equal(det['target_mask'], tm)
-    # Beamformer on all bins.  The synthetic sources separate so cleanly that at many bins a
-    # few frames carry the whole distortion mask and Phi_N is nearly singular.  There the
-    # reference's own arithmetic is the limit: blind_analytic_normalization evaluates
-    # w^H Phi_N Phi_N w as one four-operand einsum, which cancels catastrophically once
-    # cond(Phi_N)^2 eps > 1 (measured against an 80-bit evaluation: the literal formula is
-    # off by 14 % at cond 5e9, the GPU, which forms ||Phi_N w||, by 3e-8 --
-    # scratch/cfg3_debug.py).  So: the literal oracle is the yardstick where
-    # cond(Phi_N) < 1e8, the same formula evaluated as ||Phi_N w|| / |w^H Phi_N w| up to
-    # cond 1e10, and the reference channel (a cross-frequency sum that the ill-conditioned
-    # bins dominate) is handed over from the GPU unless the SNRs are sane.
+    assert np.array_equal(det['target_mask'], masks[u.target_index])
+    _beamformer_all_bins_with_referee(gpu_ctx, det, u, bf)
+    assert rel_err(x_hat, oracle.istft(det['X_hat'])) < 1e-11
+    assert np.all(np.isfinite(x_hat))
+    return x_hat, det
+
+
+def _beamformer_all_bins_with_referee(gpu_ctx, det, u, bf):
+    """The beamformer stage on ALL 513 bins of a SURVEY 8d scene, from the GPU's own
+    dereverberated tensor and masks.
+
+    On these scenes (point sources, sensor noise 60 dB down) the distortion PSD matrix is
+    nearly singular in most bins (config 3: cond(Phi_N) > 1e8 in 480 of 513 bins, > 1e12 in
+    100), and there the REFERENCE'S OWN float64 arithmetic does not evaluate its own
+    formulas: np.linalg.solve loses cond * eps, blind_analytic_normalization's four-operand
+    einsum cancels catastrophically once cond^2 * eps > 1, and the cross-frequency SNR sums
+    of the reference-channel search come out as 1e60.  Measured against an 80-bit evaluation
+    of the same formulas (tests/ext_precision.py) the literal float64 oracle is off by
+    5e-4 (median) for cond in [1e8, 1e10), by 0.7 for [1e10, 1e12) and by factors of 1e2 ...
+    1e5 beyond, while a float64 evaluation in the stable order ||Phi_N w|| / |w^H Phi_N w|
+    -- what mvdr_apply_kernel computes -- stays within 0.2 cond eps of it in every bin.
+
+    So every bin is held to a bound, none is left out:
+      * literal oracle, 1e-4, wherever the reference's float64 result is itself meaningful
+        (cond(Phi_N) < 1e8);
+      * everywhere: the extended-precision evaluation of the reference's formulas, within
+        max(1e-6, 4 cond eps) for MVDR (the error bound of a backward-stable float64 solve;
+        = 1e-4 at cond 1e11).
+    The reference channel is an argmax over SNR sums that the degenerate bins dominate: it
+    must equal the oracle's unless the oracle's own SNRs are rounding noise (> 1e12), in
+    which case the oracle's channel is forced for the comparison."""
+    from pb_chime5_amd import ops
+    import ext_precision as xp
+    eps = np.finfo(np.float64).eps
+    tm, dm = det['target_mask'], det['distortion_mask']
     Yf = det['Obs'].transpose(2, 0, 1)
     cov_x = oracle.get_power_spectral_density_matrix(Yf, tm.T)
     cov_n = oracle.get_power_spectral_density_matrix(Yf, dm.T)
     cond = np.linalg.cond(cov_n)
-    strict, good = cond < 1e8, cond < 1e10
-    assert good.mean() > 0.3, good.mean()
+    strict = cond < 1e8
+    X_got = det['X_hat']
+    ref = None
     if bf == 'gev_ban':
-        X_want = oracle.beamform_gev_from_masks(det['Obs'], tm, dm, ban=True)
-        assert rel_err(np.abs(det['X_hat'][:, strict]), np.abs(X_want[:, strict])) < TOL_STFT_MAG
+        X_lit = oracle.beamform_gev_from_masks(det['Obs'], tm, dm, ban=True)
+        c_bound = 200.0       # an eigenvector also feels the eigenvalue gap
     else:
         phi = oracle.stable_solve(cov_n, cov_x)
         mat = phi / np.maximum(np.trace(phi, axis1=-1, axis2=-2)[..., None, None].real, 1e-10)
         num = np.einsum('FdR,FdD,FDR->R', mat.conj(), cov_x, mat).real
         den = np.einsum('FdR,FdD,FDR->R', mat.conj(), cov_n, mat).real
         snr = num / np.maximum(den, 1e-10)
-        # (the SNR sums run over all bins: one bin with cond(Phi_N) >= 1e10 contributes a
-        # term that depends on the rounding of the solve, so the argmax is only comparable
-        # when every bin is well conditioned; it was 3 vs 21 at SNRs 3.5e6 vs 1.0e7 after
-        # a 1e-9 change of the WPE output on this synthetic scene)
-        if snr.max() < 1e12 and good.all():
-            assert det['ref_channel'] == int(np.argmax(snr))
-        w = oracle.get_mvdr_vector_souden(cov_x, cov_n, ref_channel=det['ref_channel'], eps=1e-10)
-        w_lit = oracle.blind_analytic_normalization(w, cov_n)
-        X_lit = oracle.apply_beamforming_vector(w_lit, Yf).T
-        if strict.any():
-            assert rel_err(np.abs(det['X_hat'][:, strict]), np.abs(X_lit[:, strict])) < TOL_STFT_MAG
-        pw = np.einsum('fab,fb->fa', cov_n, w)
-        scale = np.linalg.norm(pw, axis=-1) / np.abs(np.einsum('fa,fa->f', w.conj(), pw))
-        X_want = oracle.apply_beamforming_vector(w * scale[:, None], Yf).T
-        assert rel_err(np.abs(det['X_hat'][:, good]), np.abs(X_want[:, good])) < TOL_STFT_MAG
-    assert rel_err(x_hat, oracle.istft(det['X_hat'])) < 1e-11
-    assert np.all(np.isfinite(x_hat))
-    return x_hat, det
+        ref = int(np.argmax(snr))
+        print('oracle SNR max %.3g, reference channel oracle %d gpu %d' % (snr.max(), ref, det['ref_channel']))
+        if det['ref_channel'] != ref:
+            assert snr.max() > 1e12, (det['ref_channel'], ref, snr.max())
+            X_got = ops.mvdr_souden_from_masks(det['Obs'], tm, dm, ban=True, ref_channel=ref,
+                                               ctx=gpu_ctx)
+        w = oracle.get_mvdr_vector_souden(cov_x, cov_n, ref_channel=ref, eps=1e-10)
+        X_lit = oracle.apply_beamforming_vector(oracle.blind_analytic_normalization(w, cov_n), Yf).T
+        c_bound = 4.0
+    X_ext = xp.beamformer_all_bins(det['Obs'], tm, dm, ref, bf, workers=12)
+    n = lambda a: np.linalg.norm(a, axis=0)
+    scale = n(np.abs(X_ext))
+    e_ext = n(np.abs(X_got) - np.abs(X_ext)) / scale
+    e_lit = n(np.abs(X_got) - np.abs(X_lit)) / scale
+    o_ext = n(np.abs(X_lit) - np.abs(X_ext)) / scale
+    tol = np.maximum(1e-6, c_bound * cond * eps)
+    print('cond(Phi_N) < 1e8 in %d bins, < 1e10 in %d, < 1e12 in %d of %d'
+          % (strict.sum(), (cond < 1e10).sum(), (cond < 1e12).sum(), cond.size))
+    print('GPU vs extended precision: max of err / (cond eps) %.3f; bins where the bound exceeds '
+          '1e-4: %d; literal oracle vs extended precision: %d bins above 1e-4, max %.2e'
+          % (np.max(e_ext / (cond * eps)), (tol > 1e-4).sum(), (o_ext > 1e-4).sum(), o_ext.max()))
+    assert strict.any()
+    assert np.all(e_lit[strict] < TOL_STFT_MAG), np.flatnonzero(strict & (e_lit >= TOL_STFT_MAG))
+    assert np.all(e_ext < tol), [(int(f), e_ext[f], tol[f]) for f in np.flatnonzero(e_ext >= tol)[:8]]
 
 
-def test_config3_dev_shaped_utterance_stagewise(gpu_ctx):
-    """BASELINE.json configs[2]: a dev-shaped utterance (24 ch, reference-default context of
-    240000 samples on both sides -> about 2000 frames), checked stage by stage."""
+def test_config3_dev_shaped_utterance_all_bins(gpu_ctx, oracle_pool):
+    """BASELINE.json configs[2] as SURVEY 8d specifies it: a dev-shaped utterance (24 ch,
+    reference-default context of 240000 samples on both sides -> about 2000 frames), every
+    stage on all 513 bins."""
     from pb_chime5_amd import synthetic
     u = synthetic.config3_item(0)
-    x_hat, det = _stagewise(gpu_ctx, u, [7, 200, 480])
+    x_hat, det = _scene_all_bins(gpu_ctx, oracle_pool, u)
     assert det['Obs'].shape[1] > 1900
 
 
-def test_config5_long_rttm_segment_gev_stagewise(gpu_ctx):
-    """BASELINE.json configs[4]: 120 s, 12 channels ('outer_array_mics'), 40 EM iterations,
-    GEV + BAN beamformer (T = 7503 frames: the STFT tensor alone is 740 MB)."""
+def test_config5_long_rttm_segment_gev_all_bins(gpu_ctx, oracle_pool):
+    """BASELINE.json configs[4] as SURVEY 8d specifies it: 120 s, 12 channels
+    ('outer_array_mics'), 40 EM iterations, GEV + BAN beamformer (T = 7503 frames: the STFT
+    tensor alone is 740 MB), every stage on all 513 bins."""
     from pb_chime5_amd import synthetic
     u = synthetic.config5()
-    x_hat, det = _stagewise(gpu_ctx, u, [33, 400], bf='gev_ban', bss_iterations=40)
+    x_hat, det = _scene_all_bins(gpu_ctx, oracle_pool, u, bf='gev_ban', bss_iterations=40)
     assert det['Obs'].shape[:2] == (12, 7503)
 
 
@@ -376,6 +415,7 @@ def _all_bins_vs_oracle(gpu_ctx, pool, u, *, bf='mvdrSouden_ban', bss_iterations
         assert rel_err(det['X_hat'], wdet['X_hat']) < TOL_STFT_MAG
         assert errs['x'] < TOL_STFT_MAG
     assert errs['wpe'] < 1e-6 and errs['wpe_per_f'] < 1e-5
+    assert errs['masks'] < 1e-3, errs['masks']
     assert errs['X_mag'] < TOL_STFT_MAG and errs['X_mag_per_f'] < TOL_STFT_MAG
     return det, wdet
 
@@ -519,12 +559,8 @@ def test_config2_properties(gpu_ctx, config2_run):
 
 
 # ---------------------------------------------------------------- reference channel
-REF_MISMATCHES = []
-
-
-def _oracle_snr(wdet):
+def _oracle_snr(cov_x, cov_n):
     """The per-channel SNR get_optimal_reference_channel maximises, from the oracle's PSDs."""
-    cov_x, cov_n = wdet['cov_x'], wdet['cov_n']
     phi = oracle.stable_solve(cov_n, cov_x)
     mat = phi / np.maximum(np.trace(phi, axis1=-1, axis2=-2)[..., None, None].real, 1e-10)
     num = np.einsum('FdR,FdD,FDR->R', mat.conj(), cov_x, mat).real
@@ -532,28 +568,36 @@ def _oracle_snr(wdet):
     return num / np.maximum(den, 1e-10)
 
 
-def _check_ref_channel_or_tie(gpu_ctx, det, wdet, tag, well_conditioned=None):
+def _check_ref_channel_or_tie(gpu_ctx, det, wdet, tag, mismatches, well_conditioned=None):
     """The reference channel is one integer and must equal the oracle's.  A different
-    channel is tolerated only as a certified tie -- the oracle's own SNRs of the two
-    candidates agree to 1e-9 relative, or the scene is degenerate (a noise PSD matrix that
-    is singular to rounding in some bin: the SNR sums are then decided by the rounding of
-    the solve in the reference as well) -- and even then the beamformer is still checked,
-    with the oracle's channel forced (gss_mvdr_souden_ref) on the GPU's own tensors.
-    Every mismatch is recorded; test_reference_channel_mismatches_are_rare bounds them."""
+    channel is tolerated only when it is CERTIFIED that the oracle's own answer is not
+    defined to that precision:
+      * a tie: the oracle's SNRs of the two candidates agree to 1e-9 relative, or
+      * a degenerate scene: the oracle's SNR of one of the two candidates moves by more than
+        their gap when the noise PSD matrices are perturbed in the LAST BIT (a noise PSD
+        matrix that is singular to rounding: the SNR sums are decided by the rounding of the
+        solve in the reference as well).
+    Even then the beamformer is still checked, with the oracle's channel forced
+    (gss_mvdr_souden_ref) on the GPU's own tensors.  Every mismatch is recorded in the
+    session-wide list `mismatches`, whose fixture bounds them at teardown."""
     from pb_chime5_amd import ops
     if det['ref_channel'] == wdet['ref_channel']:
         return True
-    snr = _oracle_snr(wdet)
-    gap = abs(snr[det['ref_channel']] - snr.max()) / abs(snr.max())
+    g, o = det['ref_channel'], wdet['ref_channel']
+    snr = _oracle_snr(wdet['cov_x'], wdet['cov_n'])
+    gap = abs(snr[g] - snr[o]) / abs(snr[o])
+    rng = np.random.default_rng(0)
+    jitter = 1 + 2.2e-16 * rng.standard_normal(wdet['cov_n'].shape)
+    snr2 = _oracle_snr(wdet['cov_x'], wdet['cov_n'] * jitter)
+    moved = max(abs(snr2[g] - snr[g]) / abs(snr[g]), abs(snr2[o] - snr[o]) / abs(snr[o]))
     cond = np.linalg.cond(wdet['cov_n'])
-    degenerate = bool(cond.max() > 1e10 or snr.max() > 1e12)
-    REF_MISMATCHES.append(dict(tag=tag, gpu=det['ref_channel'], oracle=wdet['ref_channel'],
-                               gap=float(gap), cond_max=float(cond.max())))
-    assert gap < 1e-9 or degenerate, (tag, det['ref_channel'], wdet['ref_channel'], gap, cond.max())
+    mismatches.append(dict(tag=tag, gpu=g, oracle=o, gap=float(gap), last_bit_move=float(moved),
+                           cond_max=float(cond.max())))
+    assert gap < 1e-9 or moved > gap or not np.isfinite(moved), (tag, g, o, gap, moved, cond.max())
     if well_conditioned is not None:
         assert not well_conditioned, (tag, 'reference channel differs on a well-conditioned scene')
     X_forced = ops.mvdr_souden_from_masks(det['Obs'], det['target_mask'], det['distortion_mask'],
-                                          ban=True, ref_channel=wdet['ref_channel'], ctx=gpu_ctx)
+                                          ban=True, ref_channel=o, ctx=gpu_ctx)
     good = cond < 1e8
     assert good.any(), tag
     assert rel_err(np.abs(X_forced[:, good]), np.abs(wdet['X_hat'][:, good])) < TOL_STFT_MAG, tag
@@ -650,7 +694,7 @@ def test_edge_single_class_and_two_channels(gpu_ctx):
 
 
 @pytest.mark.parametrize('D,K', [(20, 4), (28, 3), (12, 6), (24, 2), (16, 3), (10, 5), (4, 3), (6, 4)])
-def test_other_channel_and_class_counts(gpu_ctx, D, K):
+def test_other_channel_and_class_counts(gpu_ctx, ref_mismatches, D, K):
     """Channel counts off the config-2 path: D = 28 / 16 / 6 take the LDS-form E-step and
     other MFMA tile counts (wpe_apply with 1 or 2 channel tiles, 3 or 4 x 8 lanes in the
     class update), D = 12 / 24 with K = 6 / 2 the register-form E-step at its limits,
@@ -667,7 +711,7 @@ def test_other_channel_and_class_counts(gpu_ctx, D, K):
                                      bss_iterations=6)
     assert np.array_equal(det['acitivity_freq'], wdet['activity_freq'])
     assert rel_err(det['Obs'], wdet['Obs']) < 1e-5
-    _check_ref_channel_or_tie(gpu_ctx, det, wdet, (D, K))
+    _check_ref_channel_or_tie(gpu_ctx, det, wdet, (D, K), ref_mismatches)
     # one point source on 24 microphones (D, K = 24, 2) leaves the noise PSD matrix singular
     # to rounding in most bins (median cond 3e11, max 3e18): there the reference's own
     # output is decided by rounding, so the beamformer is compared where cond(Phi_N) < 1e8
@@ -793,9 +837,9 @@ def test_pcm16_input_is_bit_identical_to_float64(gpu_ctx):
     assert np.array_equal(got['pcm'], want)
 
 
-def test_random_shapes_against_oracle(gpu_ctx):
+def test_random_shapes_against_oracle(gpu_ctx, ref_mismatches):
     """Seeded fuzz over channel / class / frame counts, context, WPE and EM settings, beamformer
-    and postfilter (scratch/fuzz.py is the exploratory version): every stage has partial-tile
+    and postfilter: every stage has partial-tile
     and odd-size code paths that the BASELINE shapes never visit."""
     from pb_chime5_amd import ops, synthetic
     rng = np.random.default_rng(2024)
@@ -831,7 +875,7 @@ def test_random_shapes_against_oracle(gpu_ctx):
             cond = np.linalg.cond(wdet['cov_n'])
             good = cond < 1e8
             assert good.mean() > 0.5, tag
-            if _check_ref_channel_or_tie(gpu_ctx, det, wdet, tag,
+            if _check_ref_channel_or_tie(gpu_ctx, det, wdet, tag, ref_mismatches,
                                          well_conditioned=bool(cond.max() < 1e8)):
                 assert rel_err(np.abs(det['X_hat'][:, good]), np.abs(wdet['X_hat'][:, good])) \
                     < TOL_STFT_MAG, tag
@@ -840,12 +884,3 @@ def test_random_shapes_against_oracle(gpu_ctx):
             assert rel_err(got, want) < TOL_STFT_MAG, tag
         done += 1
     assert done >= 15, done
-
-
-def test_reference_channel_mismatches_are_rare(gpu_ctx):
-    """Runs after the sweeps above (file order): how often did the GPU pick another
-    reference channel than the oracle?  Each case was already certified as a tie or a
-    degenerate scene and re-checked with the oracle's channel forced; on top of that they
-    must stay the exception."""
-    print('reference-channel mismatches:', REF_MISMATCHES)
-    assert len(REF_MISMATCHES) <= 3, REF_MISMATCHES
