@@ -74,7 +74,12 @@ __device__ inline void invert_lower_wave(cplx *A, int n, int ld, int lane) {
 // that "row / column block before, in, or after the pivot's block" is known at compile
 // time: row blocks above the pivot's are finished (no work), W entries take no column
 // beyond it, and only the pivot's own blocks need per-lane selects.
-template <int G, int NR, bool ONE_WAVE = false>
+// DIAG_RING (the WPE diagonal blocks): M is a ring of TWO rows (row j lives in slot j & 1;
+// a thread can be at most one step ahead of the slowest one, so two slots are enough) and
+// only the G x G diagonal blocks of W are formed -- the panel kernels use nothing else of
+// it (16-blocked substitution).  The caller takes U and W from `reg`, which ends up holding
+// what the full-matrix form leaves in M.
+template <int G, int NR, bool ONE_WAVE = false, bool DIAG_RING = false>
 __device__ __forceinline__ bool chol_inverse_sweep(cplx (&reg)[NR][NR], int n, cplx *M, int ld,
                                           double *dinv, int tx, int ty) {
     bool ok = true;
@@ -84,19 +89,20 @@ __device__ __forceinline__ bool chol_inverse_sweep(cplx (&reg)[NR][NR], int n, c
             const int j = G * jb + jj;
             if (j >= n) break;                      // uniform
             // the owners of row j (ty == jj, register row jb) publish it
+            cplx *Mj = M + (DIAG_RING ? (j & 1) : j) * ld;
             if (ty == jj) {
 #pragma unroll
-                for (int b = 0; b < NR; ++b) M[j * ld + tx + G * b] = reg[jb][b];
+                for (int b = 0; b < NR; ++b) Mj[tx + G * b] = reg[jb][b];
             }
             if (ONE_WAVE) wave_sync();
             else __syncthreads();
             // all LDS reads of the step are issued together, unconditionally
-            const double ajj = M[j * ld + j].x;
+            const double ajj = Mj[j].x;
             cplx ru[NR], rv[NR];
 #pragma unroll
-            for (int a = jb; a < NR; ++a) ru[a] = M[j * ld + ty + G * a];
+            for (int a = jb; a < NR; ++a) ru[a] = Mj[ty + G * a];
 #pragma unroll
-            for (int b = 0; b < NR; ++b) rv[b] = M[j * ld + tx + G * b];
+            for (int b = 0; b < NR; ++b) rv[b] = Mj[tx + G * b];
             double di = 0.0;
             if (ajj > 0.0 && isfinite(ajj)) di = rsqrt(ajj);
             else ok = false;
@@ -120,7 +126,7 @@ __device__ __forceinline__ bool chol_inverse_sweep(cplx (&reg)[NR][NR], int n, c
 #pragma unroll
                 for (int b = 0; b < NR; ++b) {
                     // entry (a, b): upper (U) when b > a, W when b < a, per thread on a == b
-                    if (b < a && b > jb) continue;
+                    if (b < a && (b > jb || DIAG_RING)) continue;
                     cplx vv;
                     if (b > a) vv = v[b];
                     else if (b < a) vv = b < jb ? v[b] : vw_jb;

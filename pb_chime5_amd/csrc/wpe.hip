@@ -365,10 +365,15 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_kernel(
 constexpr int CH_NB = 48;
 constexpr int UD_LD = CH_NB + 1;   // LDS leading dimension of the diagonal block (bank spread)
 
-// Factor the diagonal block at j0 of one frequency's matrix A (256 threads):
-// Ud <- U_JJ (upper) and W = U_JJ^-H (strictly lower), dinv <- 1 / diag(U_JJ); both are
-// also written back to A.  The block lives in registers, 3 x 3 entries per thread, and
-// one pass of nb steps builds U and W together (chol_inverse_sweep in dense_wave.h).
+// Factor the diagonal block at j0 of one frequency's matrix A (256 threads): U_JJ (upper)
+// and the inverses W_tt = U_tt^-H of its three 16 x 16 diagonal blocks (strictly lower part
+// of those blocks; nothing else of U_JJ^-H is needed by the 16-blocked substitutions of the
+// panel kernels) are written back to A, the diagonal as U_ii.  The block lives in registers,
+// 3 x 3 entries per thread, and one pass of nb steps builds U and W together
+// (chol_inverse_sweep in dense_wave.h, two-row ring in LDS): Ud = 2 * UD_LD complex,
+// dinv = CH_NB doubles.
+constexpr size_t DIAG_LDS = sizeof(cplx) * 2 * UD_LD + sizeof(double) * CH_NB;
+
 __device__ inline void chol_diag_block(cplx *A, int n, int j0, cplx *Ud, double *dinv,
                                        int32_t *zero_pivots) {
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -381,31 +386,32 @@ __device__ inline void chol_diag_block(cplx *A, int n, int j0, cplx *Ud, double 
             const int i = ty + 16 * a, k = tx + 16 * b;
             reg[a][b] = (k >= i && k < nb) ? A[(int64_t)(j0 + i) * n + j0 + k] : c_make(0.0, 0.0);
         }
-    if (!chol_inverse_sweep<16, 3>(reg, nb, Ud, UD_LD, dinv, tx, ty)) {
+    if (!chol_inverse_sweep<16, 3, false, true>(reg, nb, Ud, UD_LD, dinv, tx, ty)) {
         // rows with a non-positive pivot were zeroed (the lstsq branch of stable_solve):
         // counted for gss_last_wpe_zero_pivots()
         if (tid < nb && dinv[tid] == 0.0) atomicAdd(zero_pivots, 1);
     }
-    // rows were published unscaled: scale them, fix the diagonal, clear the padding
-    for (int idx = tid; idx < CH_NB * CH_NB; idx += blockDim.x) {
-        const int i = idx / CH_NB, k = idx - i * CH_NB;
-        cplx r = c_make(0.0, 0.0);
-        if (i < nb && k < nb) {
-            const double di = dinv[i];
-            const cplx raw = Ud[i * UD_LD + k];
-            r = k == i ? c_make(di > 0.0 ? sqrt(raw.x) : 0.0, 0.0) : c_scale(raw, di);
-            A[(int64_t)(j0 + i) * n + j0 + k] = r;
+    // the registers hold the unscaled rows: scale them, fix the diagonal
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int i = ty + 16 * a;
+        const double di = i < nb ? dinv[i] : 0.0;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int k = tx + 16 * b;
+            if (b < a || i >= nb || k >= nb) continue;       // off-diagonal W blocks: unused
+            const cplx raw = reg[a][b];
+            A[(int64_t)(j0 + i) * n + j0 + k] =
+                k == i ? c_make(di > 0.0 ? sqrt(raw.x) : 0.0, 0.0) : c_scale(raw, di);
         }
-        Ud[i * UD_LD + k] = r;
     }
-    __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void chol_diag_kernel(cplx *__restrict__ R, int n, int j0,
                                                         int32_t *__restrict__ zero_pivots) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    cplx *Ud = reinterpret_cast<cplx *>(smem);                       // CH_NB * UD_LD
-    double *dinv = reinterpret_cast<double *>(Ud + CH_NB * UD_LD);   // CH_NB
+    __shared__ __attribute__((aligned(16))) char smem[DIAG_LDS];
+    cplx *Ud = reinterpret_cast<cplx *>(smem);                       // 2 * UD_LD
+    double *dinv = reinterpret_cast<double *>(Ud + 2 * UD_LD);       // CH_NB
     chol_diag_block(R + (int64_t)blockIdx.x * n * n, n, j0, Ud, dinv, zero_pivots);
 }
 
@@ -639,21 +645,59 @@ __device__ inline void chol_update_tile(cplx *A, cplx *Z, int n, int D, int j0, 
 }
 
 // XCD-mapped 1-D grid over (tile groups, F), block 256 = 4 waves, one tile each.
+// The first `ndiag` tiles of the list are those of the NEXT diagonal block (j0 + K rows
+// onward, 48 x 48: up to 6 tiles).  Group 0 of every frequency takes all of them and then
+// factors that block right here (chol_diag_block, all 256 threads) while the other groups
+// are still updating the rest of the trailing matrix: the 35 us latency chain of the
+// diagonal sweep is hidden under the update instead of being a launch of its own between
+// two launches that wait for it (4 of the 5 chol_diag launches per solve, 0.4 ms per
+// utterance at config 2).
+constexpr int UPD_WAVES = 4;    // tiles per workgroup (8 waves: the 6 diagonal tiles in one round, but the bulk runs 7 % slower)
+
 template <int TM, int TN, bool PREFETCH>
-__global__ __launch_bounds__(256) void chol_update_kernel(cplx *__restrict__ R,
+__global__ __launch_bounds__(64 * UPD_WAVES) void chol_update_kernel(cplx *__restrict__ R,
                                                           cplx *__restrict__ P, int F, int n,
                                                           int D, int j0, int nb,
                                                           const UpdTile *__restrict__ tiles,
-                                                          int ntiles) {
+                                                          int ntiles, int ndiag, int j0_next,
+                                                          int32_t *__restrict__ zero_pivots) {
+    __shared__ __attribute__((aligned(16))) char smem[DIAG_LDS];
     // 1-D XCD-mapped grid: the tiles of one frequency run on one XCD, so its panel is
-    // fetched into one L2 instead of all eight
+    // fetched into one L2 instead of all eight.
+    // Block ids [0, F8) are the diagonal groups of all frequencies (dispatched FIRST: their
+    // latency chain must start at the beginning of the launch, not whenever the dispatcher
+    // reaches them), the rest the ordinary groups; block L of either part runs on XCD L % 8
+    // = f % 8.
+    const int F8 = ndiag > 0 ? (F + 7) / 8 * 8 : 0;
+    const bool diag_group = (int)blockIdx.x < F8;
     int f, grp;
-    if (!xcd_group_map((ntiles + 3) / 4, F, f, grp)) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile_id = grp * 4 + wave;
+    if (diag_group) {
+        f = blockIdx.x;
+        grp = 0;
+        if (f >= F) return;
+    } else {
+        const int L = blockIdx.x - F8, nsub = (ntiles - ndiag + UPD_WAVES - 1) / UPD_WAVES;
+        const int sg = L / (8 * nsub), rem = L - sg * 8 * nsub;
+        grp = rem >> 3;
+        f = sg * 8 + (rem & 7);
+        if (f >= F) return;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    cplx *A = R + (int64_t)f * n * n, *Z = P + (int64_t)f * n * D;
+    if (diag_group) {
+        __builtin_amdgcn_s_setprio(3);     // the critical path of the launch
+        for (int t = wave; t < ndiag; t += UPD_WAVES)
+            chol_update_tile<TM, TN, PREFETCH>(A, Z, n, D, j0, nb, tiles[t], lane);
+        __syncthreads();      // the block is complete and visible to the whole workgroup
+        if (wave >= 4) return;      // the sweep is a 256-thread routine
+        cplx *Ud = reinterpret_cast<cplx *>(smem);                       // 2 * UD_LD
+        double *dinv = reinterpret_cast<double *>(Ud + 2 * UD_LD);       // CH_NB
+        chol_diag_block(A, n, j0_next, Ud, dinv, zero_pivots);
+        return;
+    }
+    const int tile_id = ndiag + grp * UPD_WAVES + wave;
     if (tile_id >= ntiles) return;
-    chol_update_tile<TM, TN, PREFETCH>(R + (int64_t)f * n * n, P + (int64_t)f * n * D, n, D, j0,
-                                       nb, tiles[tile_id], lane);
+    chol_update_tile<TM, TN, PREFETCH>(A, Z, n, D, j0, nb, tiles[tile_id], lane);
 }
 
 // Blocked back substitution U G = Z, G overwrites Z:  G_J = U_JJ^-1 (Z_J - U_J,>J G_>J),
@@ -1308,7 +1352,8 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     // block J everything below it is updated once with both panels J - 1 and J (K = 96).
     constexpr int tm16 = 16, tn16 = 16;
     std::vector<UpdTile> upd;
-    std::vector<int> upd_start, upd_count, upd_j0, upd_k;
+    std::vector<int> upd_start, upd_count, upd_j0, upd_k, upd_ndiag;
+    static const bool fold_diag = getenv("GSS_CHOL_DIAG_UNFOLDED") == nullptr;
     {
         const int nblk = (n + CH_NB - 1) / CH_NB;
         static const bool paired = getenv("GSS_UPD_UNPAIRED") == nullptr;
@@ -1317,9 +1362,16 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
             const int rs = (J + 1) * CH_NB;
             const bool narrow = paired && J % 2 == 0;
             const int r_end = narrow ? std::min(rs + CH_NB, n) : n;
+            // the tiles of the next diagonal block first (group 0 factors it in the same
+            // launch, see chol_update_kernel), then everything else
+            const int d_end = std::min(rs + CH_NB, n);
+            for (int r0 = rs; r0 < d_end; r0 += tm16)
+                for (int c0 = rs; c0 < d_end; c0 += tn16)
+                    if (c0 + tn16 > r0) upd.push_back({r0, c0, 0, 0});
+            upd_ndiag.push_back(fold_diag ? (int)upd.size() - upd_start.back() : 0);
             for (int r0 = rs; r0 < r_end; r0 += tm16) {
                 for (int c0 = rs; c0 < n; c0 += tn16)
-                    if (c0 + tn16 > r0) upd.push_back({r0, c0, 0, 0});
+                    if (c0 + tn16 > r0 && !(r0 < d_end && c0 < d_end)) upd.push_back({r0, c0, 0, 0});
                 for (int cc = 0; cc < D; cc += tn16) upd.push_back({r0, cc, 1, 0});
             }
             upd_count.push_back((int)upd.size() - upd_start.back());
@@ -1483,10 +1535,11 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
             const int nblk = (n + CH_NB - 1) / CH_NB;
             for (int J = 0; J < nblk; ++J) {
                 const int j0 = J * CH_NB, nb = std::min(CH_NB, n - j0);
-                {
+                // (blocks J > 0 are factored by group 0 of the preceding trailing update)
+                if (J == 0 || upd_ndiag[J - 1] == 0) {
                     GSS_PROF(ctx, "wpe_chol_diag");
-                    hipLaunchKernelGGL(chol_diag_kernel, dim3(F), dim3(256), panel_lds, ctx->stream, R, n,
-                                       j0, zero_pivots);
+                    hipLaunchKernelGGL(chol_diag_kernel, dim3(F), dim3(256), 0, ctx->stream, R, n, j0,
+                                       zero_pivots);
                     GSS_LAUNCH_CHECK(ctx, "chol_diag_kernel");
                 }
                 {
@@ -1499,10 +1552,13 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                 const int nupd = upd_count[J];
                 if (nupd > 0) {
                     GSS_PROF(ctx, "wpe_chol_update");
-                    const dim3 g(xcd_grid((nupd + 3) / 4, F)), b(256);
+                    const int ndiag = upd_ndiag[J];
+                    const dim3 g((ndiag > 0 ? (F + 7) / 8 * 8 : 0) +
+                                 xcd_grid((nupd - ndiag + UPD_WAVES - 1) / UPD_WAVES, F)), b(64 * UPD_WAVES);
                     const UpdTile *tl = upd_dev + upd_start[J];
-                    hipLaunchKernelGGL((chol_update_kernel<1, 1, true>), g, b, 0, ctx->stream, R, P,
-                                       F, n, D, upd_j0[J], std::min(upd_k[J], n - upd_j0[J]), tl, nupd);
+                    hipLaunchKernelGGL((chol_update_kernel<1, 1, true>), g, b, 0, ctx->stream, R, P, F, n, D, upd_j0[J],
+                                       std::min(upd_k[J], n - upd_j0[J]), tl, nupd, ndiag,
+                                       (J + 1) * CH_NB, zero_pivots);
                     GSS_LAUNCH_CHECK(ctx, "chol_update_kernel");
                 }
             }
