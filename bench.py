@@ -150,6 +150,46 @@ def _cpu_worker(job):
     return out
 
 
+def _cpu_worker_config3(job):
+    """One item of BASELINE configs[2] (dev-shaped, 24 ch, 2 x 15 s context) through the oracle
+    on one core: the pool hands the items out on request, like dlp_mpi's master
+    (/root/reference/pb_chime5/core.py:381).  WPE + EM on `sample_bins` of the 513 bins and
+    extrapolated, everything else in full (see _cpu_worker)."""
+    _limit_threads()
+    sys.path.insert(0, str(REPO / 'oracle'))
+    import gss_oracle as oracle
+    path, base, core, sample_bins = job
+    data = np.load(path)
+    pcm, act = data[f'pcm{base}'], data[f'act{base}'].astype(bool)
+    ctx, core_max = int(data['context']), int(data['core_max'])
+    a, b = ctx + core, ctx + core_max
+    obs = np.concatenate([pcm[:, :a], pcm[:, b:]], axis=1).astype(np.float64) / 2 ** 15
+    activity = np.concatenate([act[:, :a], act[:, b:]], axis=1)
+    ex = dict(start={'original': 0}, start_orig={'original': ctx},
+              end_orig={'original': obs.shape[1] - ctx}, end={'original': obs.shape[1]})
+    F = 513
+    bins = np.linspace(0, F - 1, sample_bins).astype(int)
+    t0 = time.perf_counter()
+    Obs = oracle.stft(obs)
+    act_f = oracle.activity_time_to_frequency(activity, 1024, 256, True)
+    t_full = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    Xs = oracle.wpe_block(Obs[..., bins], WORKLOAD['wpe_taps'], WORKLOAD['wpe_delay'],
+                          WORKLOAD['wpe_iterations'])
+    post = oracle.gss_block(Xs, act_f, WORKLOAD['bss_iterations'], WORKLOAD['bss_iterations_post'])
+    t_bins = time.perf_counter() - t0
+    masks = np.repeat(post[..., :1], F, axis=-1)
+    t0 = time.perf_counter()
+    sf, ef = oracle.start_end_context_frames(ex, 1024, 256, True)
+    masks[:, :sf] = 0
+    masks[:, -ef:] = 0
+    oracle.istft(oracle.beamform_mvdr_souden_from_masks(Obs, masks[0], np.sum(masks[1:], axis=0),
+                                                        ban=True))
+    t_full += time.perf_counter() - t0
+    return dict(seconds=obs.shape[1] / SR, measured_s=t_full + t_bins,
+                estimate_s=t_full + t_bins * F / float(sample_bins))
+
+
 def _host_cpu():
     model, phys = None, set()
     try:
@@ -197,7 +237,7 @@ def _host_cpu():
     return model or 'unknown', physical, logical, mem_gb, quota
 
 
-def cpu_baseline(utt2, sample_bins=24, max_workers=None, with_config5=True):
+def cpu_baseline(utt2, sample_bins=24, max_workers=None, with_config5=True, with_config3=True):
     """the NumPy oracle (kind 'port') on W = physical cores - 1
     single-threaded worker processes, every worker enhancing whole utterances at the same
     time (so the figure includes what the cores cost each other in memory bandwidth)."""
@@ -220,6 +260,8 @@ def cpu_baseline(utt2, sample_bins=24, max_workers=None, with_config5=True):
                                              'OPENBLAS_NUM_THREADS')}
     tmp = tempfile.NamedTemporaryFile(suffix='.npz', delete=False)
     tmp.close()
+    tmp3 = tempfile.NamedTemporaryFile(suffix='.npz', delete=False)
+    tmp3.close()
     try:
         extra = {}
         if utt5 is not None:
@@ -237,9 +279,37 @@ def cpu_baseline(utt2, sample_bins=24, max_workers=None, with_config5=True):
         with ProcessPoolExecutor(W, mp_context=mp.get_context('spawn')) as pool:
             futures = [pool.submit(_cpu_worker, (tmp.name, sample_bins, 2)) for _ in range(W)]
             res = [f.result(timeout=600) for f in futures]
-        wall = time.perf_counter() - t0
+            wall = time.perf_counter() - t0
+            # ---- all-core aggregate on a 2 W-item subset of config 3, items
+            # handed out on request (the executor's queue), longest first
+            config3 = None
+            if with_config3:
+                pool3 = Config3Pool(2 * W, 2)
+                np.savez(tmp3.name, context=pool3.context, core_max=pool3.core_max,
+                         **{f'pcm{i}': b[0] for i, b in enumerate(pool3.bases)},
+                         **{f'act{i}': b[1] for i, b in enumerate(pool3.bases)})
+                order = np.argsort(pool3.num_samples)[::-1]
+                bins3 = max(sample_bins // 3, 2)
+                t3 = time.perf_counter()
+                futures = [pool.submit(_cpu_worker_config3,
+                                       (tmp3.name, int(i) % 2, pool3.cores[int(i)], bins3))
+                           for i in order]
+                res3 = [f.result(timeout=900) for f in futures]
+                wall3 = time.perf_counter() - t3
+                secs3 = sum(r['seconds'] for r in res3)
+                est3 = sum(r['estimate_s'] for r in res3)
+                config3 = {
+                    'aggregate_value': W * secs3 / est3, 'per_core_value': secs3 / est3,
+                    'items': len(res3), 'utterance_seconds': secs3,
+                    'core_seconds_extrapolated': est3, 'wall_s_sampled': wall3,
+                    'sample': f'BASELINE configs[2]: the first {len(res3)} = 2 W dev-shaped items, '
+                              f'pulled longest first from one queue by {W} single-thread workers; per '
+                              f'item WPE + EM on {bins3} of 513 bins (extrapolated), the rest in full; '
+                              'aggregate = W x audio seconds / extrapolated core seconds'}
     finally:
         os.unlink(tmp.name)
+        if os.path.exists(tmp3.name):
+            os.unlink(tmp3.name)
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)
@@ -265,6 +335,7 @@ def cpu_baseline(utt2, sample_bins=24, max_workers=None, with_config5=True):
                     'sample': 'BASELINE configs[0] (4 ch, 5 s, WPE off, 5 EM iterations), 2 whole '
                               'utterances per worker, nothing sampled'},
         'config5': config5,
+        'config3': config3,
         'wall_s': wall,
         'sample': (f'{W} worker processes (usable physical cores - 1, like `mpiexec -np W+1`), each 1 '
                    f'thread, all running at the same time; per worker one config-2 utterance: '
@@ -325,18 +396,40 @@ class Config3Pool:
         return self.num_samples[i] / SR
 
 
-def run_session(pipe, indices, get_item):
+def run_session(pipe, indices, get_item, clock=None):
     """What Enhancer._enhance_and_write does per GPU: keep the pipeline full, pop the
-    oldest result when it is.  Returns the number of utterances handled."""
+    oldest result when it is.  Returns the number of utterances handled.  `clock` (a dict)
+    collects where the host thread of this rank spends its time: waiting for the next index
+    of the shared queue, preparing the item on the host, uploading + enqueueing, and blocked
+    on the GPU for the oldest result (download included)."""
     count = 0
-    for i in indices:
+    clock = clock if clock is not None else {}
+    for k in ('queue_wait_s', 'host_prepare_s', 'enqueue_s', 'gpu_wait_s'):
+        clock.setdefault(k, 0.0)
+    it = iter(indices)
+    while True:
+        t0 = time.perf_counter()
+        try:
+            i = next(it)
+        except StopIteration:
+            break
+        t1 = time.perf_counter()
         prepared = get_item(i)
+        t2 = time.perf_counter()
         if pipe.full():
             pipe.pop()
+        t3 = time.perf_counter()
         pipe.enqueue(i, *prepared)
+        t4 = time.perf_counter()
+        clock['queue_wait_s'] += t1 - t0
+        clock['host_prepare_s'] += t2 - t1
+        clock['gpu_wait_s'] += t3 - t2
+        clock['enqueue_s'] += t4 - t3
         count += 1
+    t0 = time.perf_counter()
     while len(pipe):
         pipe.pop()
+    clock['gpu_wait_s'] += time.perf_counter() - t0
     return count
 
 
@@ -476,6 +569,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
+    def gather_over_ranks(values):
+        """[values of rank 0, values of rank 1, ...] (a short list of floats per rank)."""
+        if dist is None:
+            return [list(map(float, values))]
+        t = torch.zeros((world, len(values)), dtype=torch.float64, device=coll_device)
+        t[rank] = torch.tensor(list(values), dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().tolist()
+
     params = ops.make_params(wpe=True, wpe_taps=WORKLOAD['wpe_taps'],
                              wpe_delay=WORKLOAD['wpe_delay'],
                              wpe_iterations=WORKLOAD['wpe_iterations'],
@@ -504,10 +606,14 @@ def main():
         def get(i):
             handled.append(i)
             return pool.item(i)
-        run_session(pipe, mine, get)
+        clock = {}
+        run_session(pipe, mine, get, clock)
         local = time.perf_counter() - t0
         barrier()
         wall = max_over_ranks(time.perf_counter() - t0)
+        per_rank = gather_over_ranks([local, len(handled), sum(pool.seconds(i) for i in handled),
+                                      clock['queue_wait_s'], clock['host_prepare_s'],
+                                      clock['enqueue_s'], clock['gpu_wait_s']])
         secs = sum_over_ranks(sum(pool.seconds(i) for i in handled))
         total = sum_over_ranks(len(handled))
         busiest = max_over_ranks(len(handled))
@@ -529,6 +635,11 @@ def main():
             'ms_per_utterance': 1e3 * wall / items * world,
             'items_on_busiest_rank': int(busiest), 'slowest_rank_busy_s': slowest_local,
             'host_generation_s': t_gen,
+            # one row per rank: where its host thread spent the session (a rank whose
+            # gpu_wait_s is small and host_prepare_s + enqueue_s large is host bound)
+            'per_rank': [dict(rank=r, busy_s=v[0], items=int(v[1]), utterance_seconds=v[2],
+                              queue_wait_s=v[3], host_prepare_s=v[4], enqueue_s=v[5],
+                              gpu_wait_s=v[6]) for r, v in enumerate(per_rank)],
         }
 
     if args.config == 3:

@@ -98,10 +98,21 @@ class Activity:
                     use_ArrayIntervall=True)[session_id])
             return self._cached[1]
         if self.type == 'path':
-            import pickle
             with open(Path(self.path) / f'{session_id}.pkl', 'rb') as fd:
-                return pickle.load(fd)
+                return _ReferenceUnpickler(fd).load()
         raise ValueError(self.type)
+
+
+class _ReferenceUnpickler(__import__('pickle').Unpickler):
+    """Activity pickles written with the reference (core.py:135-139, e.g. the alignment-based
+    activity of its sacred runs) name classes of the `pb_chime5` package, above all
+    pb_chime5.utils.intervall_array.ArrayIntervall; they resolve to their counterparts here
+    (same attributes), so such a file loads without the reference installed."""
+
+    def find_class(self, module, name):
+        if module == 'pb_chime5' or module.startswith('pb_chime5.'):
+            module = 'pb_chime5_amd' + module[len('pb_chime5'):]
+        return super().find_class(module, name)
 
 
 @dataclass
