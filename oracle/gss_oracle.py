@@ -234,6 +234,8 @@ def get_power(signal, psd_context=0):
     t-p..t+p that exist: np.correlate with ones(2p + 1) in 'full' mode, cropped to the T
     centred lags and divided by the same correlation of an all-ones signal."""
     power = np.mean(signal.real ** 2 + signal.imag ** 2, axis=-2)
+    if np.isposinf(psd_context):            # upstream: the global mean for every frame
+        return np.broadcast_to(np.mean(power, axis=-1, keepdims=True), power.shape).copy()
     if psd_context != 0:
         assert int(psd_context) == psd_context and psd_context > 0, psd_context
         p = int(psd_context)

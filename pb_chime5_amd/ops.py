@@ -141,18 +141,24 @@ def _ftd_to_host_dtf(ctx, buf, D, T, F):
     return ctx.to_host(tmp, (D, T, F), np.complex128)
 
 
+PSD_CONTEXT_ALL = 2 ** 31 - 1      # "every frame": what np.inf means upstream
+
+
 def check_psd_context(psd_context):
-    """nara_wpe.wpe.get_power accepts an int (frames either side), a (left, right) tuple and
-    np.inf (global mean); the kernels implement the symmetric integer window
-    (core.py:56,583 passes an int, default 0).  Everything else is refused in ONE place with
-    NotImplementedError -- never truncated, never a TypeError / OverflowError from int()."""
+    """nara_wpe.wpe.get_power takes a non-negative integer (frames either side of t, default 0:
+    core.py:56,583) or np.inf (the mean over all frames); both are implemented -- np.inf as a
+    window that always covers the whole utterance.  Everything else ((left, right) tuples --
+    an argument of upstream's window_mean, not of get_power --, fractions, negative values)
+    is refused in ONE place with NotImplementedError: never truncated, never a TypeError /
+    OverflowError out of int()."""
+    if isinstance(psd_context, (float, np.floating)) and np.isposinf(psd_context):
+        return PSD_CONTEXT_ALL
     ok = isinstance(psd_context, (int, np.integer)) and not isinstance(psd_context, bool)
     if not ok and isinstance(psd_context, (float, np.floating)):
         ok = np.isfinite(psd_context) and float(psd_context).is_integer()
-    if not ok or psd_context < 0 or psd_context > 2 ** 31 - 1:
+    if not ok or psd_context < 0 or psd_context > PSD_CONTEXT_ALL:
         raise NotImplementedError(
-            f'psd_context={psd_context!r}: only a non-negative integer number of frames is '
-            'implemented (no (left, right) tuple, no np.inf)')
+            f'psd_context={psd_context!r}: a non-negative integer number of frames or np.inf')
     return int(psd_context)
 
 

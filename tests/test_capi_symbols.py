@@ -73,11 +73,11 @@ def test_psd_context_is_validated_in_one_place():
     from pb_chime5_amd import ops
     assert ops.check_psd_context(0) == 0 and ops.check_psd_context(np.int64(3)) == 3
     assert ops.check_psd_context(2.0) == 2
-    for bad in (np.inf, float('nan'), 1.5, (1, 2), -1, None, 'a', True):
+    assert ops.check_psd_context(np.inf) == ops.PSD_CONTEXT_ALL == 2 ** 31 - 1
+    for bad in (-np.inf, float('nan'), 1.5, (1, 2), -1, None, 'a', True):
         with pytest.raises(NotImplementedError):
             ops.check_psd_context(bad)
-    with pytest.raises(NotImplementedError):
-        ops.make_params(wpe_psd_context=np.inf)
+    assert ops.make_params(wpe_psd_context=np.inf).wpe_psd_context == 2 ** 31 - 1
 
 
 def test_abi_revision_is_checked_on_load(tmp_path):

@@ -171,13 +171,13 @@ def test_wpe_config2_bins_within_oracle_noise_of_extended_precision(gpu_ctx, gol
     assert gpu_ctx.last_wpe_zero_pivots() == 0
 
 
-@pytest.mark.parametrize('psd_context', [1, 3, 400])
+@pytest.mark.parametrize('psd_context', [1, 3, 17, 400, np.inf])
 def test_wpe_psd_context_matches_oracle(gpu_ctx, psd_context):
     """wpe_psd_context > 0 (core.py:56,583 -> nara_wpe get_power): the frame power is the
     mean over the existing frames of [t - p, t + p] before the floor and the inversion;
     p = 400 > T / 2 exercises windows cut on both sides at once."""
     from pb_chime5_amd import ops
-    rng = np.random.default_rng(31 + psd_context)
+    rng = np.random.default_rng(31 + (0 if np.isinf(psd_context) else psd_context))
     D, T, F, taps, delay = 6, 523, 5, 4, 2
     Y = _reverberant(rng, D, T, F)
     Y[:, 40:60] *= 0.1                        # a quiet passage: smoothing changes its weights
@@ -189,8 +189,9 @@ def test_wpe_psd_context_matches_oracle(gpu_ctx, psd_context):
     # closed form of the smoothed power the oracle uses
     p = oracle.get_power(Y[..., 0], psd_context)
     raw = np.mean(np.abs(Y[..., 0]) ** 2, axis=0)
-    for t in (0, 1, psd_context, T // 2, T - 2, T - 1):
-        lo, hi = max(0, t - psd_context), min(T - 1, t + psd_context)
+    pc = T if np.isinf(psd_context) else psd_context
+    for t in (0, 1, min(pc, T - 1), T // 2, T - 2, T - 1):
+        lo, hi = max(0, t - pc), min(T - 1, t + pc)
         assert abs(p[t] - raw[lo:hi + 1].mean()) <= 1e-12 * raw.max()
     with pytest.raises(NotImplementedError):
         ops.wpe_dtf(Y, taps, delay, 1, (1, 2), ctx=gpu_ctx)
