@@ -1353,7 +1353,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     constexpr int tm16 = 16, tn16 = 16;
     std::vector<UpdTile> upd;
     std::vector<int> upd_start, upd_count, upd_j0, upd_k, upd_ndiag;
-    static const bool fold_diag = getenv("GSS_CHOL_DIAG_UNFOLDED") == nullptr;
+    const bool fold_diag = getenv("GSS_CHOL_DIAG_UNFOLDED") == nullptr;
     {
         const int nblk = (n + CH_NB - 1) / CH_NB;
         static const bool paired = getenv("GSS_UPD_UNPAIRED") == nullptr;
@@ -1384,7 +1384,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                 "wpe: taps*D=%d too large", n);
     static_assert(sizeof(CorrTile) == sizeof(UpdTile), "tile structs share one buffer");
     if (ctx->wpe_tiles_key[0] != taps || ctx->wpe_tiles_key[1] != delay ||
-        ctx->wpe_tiles_key[2] != D || ctx->wpe_tiles_key[3] != corr_ts) {
+        ctx->wpe_tiles_key[2] != D || ctx->wpe_tiles_key[3] != corr_ts + (fold_diag ? 0 : 16)) {
         GSS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (!ctx->wpe_tiles)
             GSS_HIP_CHECK(ctx, hipMalloc(&ctx->wpe_tiles, sizeof(CorrTile) * (1024 + 4096 + 1)));
@@ -1397,7 +1397,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         ctx->wpe_tiles_key[0] = taps;
         ctx->wpe_tiles_key[1] = delay;
         ctx->wpe_tiles_key[2] = D;
-        ctx->wpe_tiles_key[3] = corr_ts;
+        ctx->wpe_tiles_key[3] = corr_ts + (fold_diag ? 0 : 16);
     }
     CorrTile *tiles_dev = reinterpret_cast<CorrTile *>(ctx->wpe_tiles);
     UpdTile *upd_dev = reinterpret_cast<UpdTile *>(tiles_dev + 1024);

@@ -756,7 +756,8 @@ def test_kernel_variants_agree(gpu_ctx, D, monkeypatch):
     assert good.mean() > 0.05, good.mean()
     for env in ({'GSS_CORR_TS': '2' if D <= 12 else '1'}, {'GSS_CORR_4M': '1', 'GSS_APPLY_4M': '1'},
                 {'GSS_MSTEP_TILED': '1'}, {'GSS_ESTEP_LDS': '1'}, {'GSS_FORCE_EIGH': '1'},
-                {'GSS_CORR_NW': '2'}, {'GSS_APPLY_NWV': '2'}, {'GSS_APPLY_PH': '1'}, {'GSS_APPLY_PH': '2'},
+                {'GSS_CORR_NW': '2'}, {'GSS_APPLY_NWV': '2'}, {'GSS_CHOL_DIAG_UNFOLDED': '1'},
+                {'GSS_APPLY_PH': '1'}, {'GSS_APPLY_PH': '2'},
                 {'GSS_APPLY_PH': '3'}, {'GSS_APPLY_PH': '4'}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
