@@ -61,7 +61,7 @@ typedef enum {
 /* Limits of the built kernels. */
 #define GSS_MAX_CHANNELS 32    /* reference asserts D < 30 (beamforming_wrapper.py:44) */
 #define GSS_MAX_CLASSES 19     /* pb_bss asserts K < 20 (CACGMMTrainer.fit); CHiME-5/6: K <= 5 */
-#define GSS_MAX_STFT_SIZE 4096
+#define GSS_MAX_STFT_SIZE 4096 /* any even length; powers of two take the FFT kernels, others a direct DFT */
 
 /* ABI revision of this header.  Bumped whenever an entry point changes its argument list
  * or a struct its layout (round 2 added `psd_context` to gss_wpe and `wpe_psd_context` to

@@ -306,8 +306,9 @@ extern "C" int64_t gss_samples_to_stft_frames(int64_t samples, int size, int shi
 extern "C" int gss_set_windows(gss_ctx *ctx, int size, int shift, const double *analysis,
                                const double *synthesis) {
     if (!ctx || !analysis || !synthesis) return GSS_ERR_INVALID;
-    GSS_REQUIRE(ctx, size >= 4 && size <= GSS_MAX_STFT_SIZE && (size & (size - 1)) == 0,
-                GSS_ERR_UNSUPPORTED, "stft size %d: need a power of two in [4, %d]", size,
+    // (powers of two take the radix-2 kernels, other even lengths a direct DFT)
+    GSS_REQUIRE(ctx, size >= 4 && size <= GSS_MAX_STFT_SIZE && size % 2 == 0,
+                GSS_ERR_UNSUPPORTED, "stft size %d: need an even length in [4, %d]", size,
                 GSS_MAX_STFT_SIZE);
     GSS_REQUIRE(ctx, shift > 0 && shift <= size && size % shift == 0, GSS_ERR_INVALID,
                 "stft shift %d must divide size %d", shift, size);
@@ -328,7 +329,7 @@ extern "C" int gss_set_windows(gss_ctx *ctx, int size, int shift, const double *
     }
     tw[0].x = 1.0;
     tw[0].y = 0.0;
-    if (size >= 4) {
+    if (size % 4 == 0) {
         tw[size / 4].x = 0.0;
         tw[size / 4].y = -1.0;
     }

@@ -178,6 +178,77 @@ __global__ __launch_bounds__(FFT_THREADS) void istft_frames_kernel(
     }
 }
 
+// ---- any even window length (not a power of two): direct DFT.  The reference's default is
+// 1024 and every BASELINE config uses it; get_enhancer(stft_size=...) (core.py:577) takes any
+// length though, so other sizes get a plain O(size^2) transform per frame -- a few ms per
+// utterance instead of 0.2, and the same numbers as numpy's rfft / irfft to 1e-15 relative.
+// tw holds exp(-2 pi i j / size) for j < size / 2; the second half is its negative.
+__device__ __forceinline__ cplx tw_full(const cplx *tw, int j, int half) {
+    const cplx w = tw[j < half ? j : j - half];
+    return j < half ? w : c_make(-w.x, -w.y);
+}
+
+// grid (T, D), block 256: one frame of one channel; thread = frequency bins tid, tid + 256, ...
+template <typename TIn>
+__global__ __launch_bounds__(FFT_THREADS) void stft_dft_kernel(
+    const TIn *__restrict__ x, double in_scale, int D, int64_t N, int64_t T, int size, int shift,
+    int pad, const double *__restrict__ window, const cplx *__restrict__ twiddle,
+    cplx *__restrict__ Y) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx *tw = reinterpret_cast<cplx *>(smem);                   // size / 2
+    double *xw = reinterpret_cast<double *>(tw + size / 2);      // size
+    const int64_t t = blockIdx.x;
+    const int d = blockIdx.y, half = size / 2, F = half + 1;
+    const int64_t n0 = t * shift - pad;
+    for (int i = threadIdx.x; i < half; i += blockDim.x) tw[i] = twiddle[i];
+    for (int i = threadIdx.x; i < size; i += blockDim.x) {
+        const int64_t n = n0 + i;
+        xw[i] = (n >= 0 && n < N) ? ((double)x[(int64_t)d * N + n] * in_scale) * window[i] : 0.0;
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        double re = 0.0, im = 0.0;
+        int j = 0;                                  // (n f) mod size
+        for (int n = 0; n < size; ++n) {
+            const cplx w = tw_full(tw, j, half);
+            re = fma(xw[n], w.x, re);
+            im = fma(xw[n], w.y, im);
+            j += f;
+            if (j >= size) j -= size;
+        }
+        if (f == 0 || f == half) im = 0.0;          // rfft: DC and Nyquist are real
+        Y[((int64_t)f * T + t) * D + d] = c_make(re, im);
+    }
+}
+
+// grid (T), block 256: one frame; thread = samples tid, tid + 256, ...
+__global__ __launch_bounds__(FFT_THREADS) void istft_dft_kernel(
+    const cplx *__restrict__ X, int64_t T, int size, const double *__restrict__ syn,
+    const cplx *__restrict__ twiddle, double *__restrict__ frm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx *tw = reinterpret_cast<cplx *>(smem);                   // size / 2
+    cplx *xs = tw + size / 2;                                    // F
+    const int64_t t = blockIdx.x;
+    const int half = size / 2, F = half + 1;
+    for (int i = threadIdx.x; i < half; i += blockDim.x) tw[i] = twiddle[i];
+    for (int f = threadIdx.x; f < F; f += blockDim.x) xs[f] = X[t * F + f];
+    __syncthreads();
+    const double scale = 1.0 / (double)size;
+    for (int i = threadIdx.x; i < size; i += blockDim.x) {
+        // irfft: x_i = (X_0 + (-1)^i X_half + 2 sum_{0 < k < half} Re(X_k e^{+2 pi i i k / size})) / size
+        double acc = xs[0].x + ((i & 1) ? -xs[half].x : xs[half].x);
+        int j = i;                                  // (i k) mod size for k = 1
+        for (int k = 1; k < half; ++k) {
+            const cplx w = tw_full(tw, j, half);    // e^{-i theta}: Re(X conj(w)) = Xr wr + Xi wi
+            acc = fma(2.0 * xs[k].x, w.x, acc);
+            acc = fma(2.0 * xs[k].y, w.y, acc);
+            j += i;
+            if (j >= size) j -= size;
+        }
+        frm[t * size + i] = syn[i] * (acc * scale);
+    }
+}
+
 // Overlap-add in increasing frame order (np.add.at upstream), then drop the
 // fading pad.
 __global__ void istft_ola_kernel(const double *__restrict__ frm, int64_t T, int size, int shift,
@@ -327,6 +398,18 @@ int stft_run(gss_ctx *ctx, const void *x, int in_type, int D, int64_t N, int fad
     const double *xd = static_cast<const double *>(x);
     const int16_t *xi = static_cast<const int16_t *>(x);
     const double pcm = 1.0 / 32768.0;
+    if ((size & (size - 1)) != 0) {                 // not a power of two: direct DFT
+        const size_t lds = sizeof(cplx) * (size / 2) + sizeof(double) * size;
+        const dim3 grid((unsigned)T, (unsigned)D);
+        if (in_type == 0)
+            hipLaunchKernelGGL((stft_dft_kernel<double>), grid, dim3(FFT_THREADS), lds, ctx->stream, xd,
+                               1.0, D, N, T, size, shift, pad, ctx->win_analysis, ctx->twiddle, Y);
+        else
+            hipLaunchKernelGGL((stft_dft_kernel<int16_t>), grid, dim3(FFT_THREADS), lds, ctx->stream,
+                               xi, pcm, D, N, T, size, shift, pad, ctx->win_analysis, ctx->twiddle, Y);
+        GSS_LAUNCH_CHECK(ctx, "stft_dft_kernel");
+        return GSS_OK;
+    }
     // 2 pairs (4 channels, 36 KB of LDS) per workgroup: 4 workgroups per CU hide the ten
     // barriers of the radix-2 passes better than 2 workgroups of 4 pairs (0.20 vs 0.24 ms)
     if (size <= 1024) {
@@ -346,7 +429,13 @@ int istft_run(gss_ctx *ctx, const cplx *X, int64_t T, int fading, double *x) {
     const int64_t n_out = gss_istft_num_samples(T, size, shift, fading);
     double *frm = arena_alloc_t<double>(ctx, (size_t)T * size);
     GSS_REQUIRE(ctx, frm, GSS_ERR_NOMEM, "istft workspace");
-    {
+    if ((size & (size - 1)) != 0) {
+        GSS_PROF(ctx, "istft_frames");
+        const size_t lds = sizeof(cplx) * (size / 2 + size / 2 + 1);
+        hipLaunchKernelGGL(istft_dft_kernel, dim3((unsigned)T), dim3(FFT_THREADS), lds, ctx->stream, X,
+                           T, size, ctx->win_synthesis, ctx->twiddle, frm);
+        GSS_LAUNCH_CHECK(ctx, "istft_dft_kernel");
+    } else {
         GSS_PROF(ctx, "istft_frames");
         size_t lds = sizeof(cplx) * (size + size / 2);
         hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)((T + 1) / 2)), dim3(FFT_THREADS),

@@ -774,13 +774,30 @@ def test_kernel_variants_agree(gpu_ctx, D, monkeypatch):
             assert rel_err(other, base) < TOL_STFT_MAG, (env, rel_err(other, base))
 
 
+def test_pipeline_with_a_window_that_is_not_a_power_of_two(gpu_ctx):
+    """get_enhancer(stft_size=400, stft_shift=100) (core.py:577-579 takes any length): the whole
+    pipeline on the direct-DFT STFT / iSTFT kernels against the oracle."""
+    from pb_chime5_amd import synthetic
+    from pb_chime5_amd.core import get_enhancer
+    u = synthetic.tiny(seed=33, num_channels=5, num_samples=20000, num_speakers=2, context=2000)
+    enh = get_enhancer(stft_size=400, stft_shift=100, wpe_tabs=3, bss_iterations=4)
+    got = enh.enhance_observation(u.obs, u.activity, u.speaker_id, ex=u.ex)
+    want = oracle.enhance_observation(u.obs, u.activity_array, u.target_index, u.ex, wpe_taps=3,
+                                      bss_iterations=4, stft_size=400, stft_shift=100,
+                                      gss_fn=oracle.gss_block_batched)
+    assert got.shape == want.shape
+    assert rel_err(got, want) < 1e-5
+
+
 def test_unsupported_sizes_fail_loudly(gpu_ctx):
     from pb_chime5_amd import ops
     # pb_bss CACGMMTrainer.fit: assert K < 20 -- an AssertionError in the reference too
     with pytest.raises(AssertionError):
         ops.enhance_observation(np.zeros((2, 4000)), np.ones((20, 4000), bool), 0, 0, 0)
     with pytest.raises(NotImplementedError):
-        ops.stft(np.zeros(4000), size=1000, shift=250)
+        ops.stft(np.zeros(4000), size=15, shift=5)          # odd window length
+    with pytest.raises(NotImplementedError):
+        ops.stft(np.zeros(40000), size=8192, shift=2048)
     with pytest.raises(ValueError):
         ops.enhance_observation(np.zeros((2, 4000)), np.ones((2, 100), bool), 0, 0, 0)
 

@@ -24,7 +24,9 @@ def test_mfma_f64_fragment_layout(gpu_ctx):
 
 
 # ---------------------------------------------------------------- STFT / iSTFT
-@pytest.mark.parametrize('size,shift', [(1024, 256), (512, 128), (64, 16), (2048, 512)])
+# (1000 / 400 / 60: not powers of two -- the direct-DFT kernels)
+@pytest.mark.parametrize('size,shift', [(1024, 256), (512, 128), (64, 16), (2048, 512), (1000, 250),
+                                        (400, 100), (60, 20)])
 @pytest.mark.parametrize('D,N', [(1, 5000), (4, 8000), (5, 7777), (24, 4096), (9, 300)])
 @pytest.mark.parametrize('fading', [True, False])
 def test_stft_matches_oracle(gpu_ctx, size, shift, D, N, fading):
@@ -64,7 +66,8 @@ def test_stft_leading_axes_and_shapes(gpu_ctx):
 
 
 @pytest.mark.parametrize('size,shift,T', [(1024, 256, 37), (1024, 256, 38), (64, 16, 131),
-                                          (512, 128, 1), (512, 256, 20)])
+                                          (512, 128, 1), (512, 256, 20), (1000, 250, 33),
+                                          (60, 20, 50)])
 @pytest.mark.parametrize('fading', [True, False])
 def test_istft_matches_oracle(gpu_ctx, size, shift, T, fading):
     from pb_chime5_amd import ops
