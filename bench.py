@@ -473,7 +473,20 @@ def em_loop_entry(prof, steps, iterations, F, T, D, K, roofline):
     size = dict(F=F, T=T, D=D, K=K, taps=1, N=0)
     flops = sum(roofline.kernel_work(n, **size)['flops'] for n in ('em_estep', 'em_mstep', 'em_chol'))
     sec = ms_iter * 1e-3
+    # the E-step alone against the roof that binds it: the scalar data cache (its model rows are
+    # wave-uniform s_load operands; ceiling measured by tools/micro/smem_bench.hip)
+    estep = None
+    if 'em_estep' in prof and D in (4, 10, 12, 20, 24) and 2 <= K <= 6:
+        e_sec = prof['em_estep']['ms'] / prof['em_estep']['calls'] * 1e-3
+        rate = roofline.estep_scalar_bytes(F, T, D, K) / e_sec / roofline.NUM_CUS / (roofline.CLOCK_GHZ * 1e9)
+        estep = {'scalar_cache_bytes_per_launch': roofline.estep_scalar_bytes(F, T, D, K),
+                 'bytes_per_cycle_per_cu': rate,
+                 'measured_ceiling': roofline.PEAK_SMEM_BYTES_PER_CYCLE_PER_CU,
+                 'scalar_cache_frac': rate / roofline.PEAK_SMEM_BYTES_PER_CYCLE_PER_CU,
+                 'valu_f64_frac': roofline.kernel_work('em_estep', **size)['flops'] / e_sec / 1e12
+                 / roofline.PEAK_F64_TFLOPS}
     return {
+        'estep_binding_roof': estep,
         'channels': D, 'frames': T, 'classes': K, 'ms_per_iteration': ms_iter,
         'kernel_ms_per_iteration': {n: prof[n]['ms'] / steps / iterations for n in names},
         'algorithmic_bytes_per_iteration': by,

@@ -13,6 +13,20 @@ figures of SURVEY.md section 8d (written for complex64) are doubled:
 # * 1024 SIMDs * 2.4 GHz = 78.6e12); the guide lists no f64 row.
 PEAK_HBM_GBS = 8000.0
 PEAK_F64_TFLOPS = 78.6
+# Scalar data cache: what one CU can feed its waves through s_load_dwordx16, MEASURED
+# (tools/micro/smem_bench.hip, profiles/r03_smem_bench.txt: 16 waves per CU streaming 64-byte
+# lines that hit the cache, four requests per wait: 122.7 loads / us / CU = 3.27 bytes per cycle
+# per CU at 2.4 GHz; one request per wait: 2.67).  The register-form E-step takes its model
+# rows -- wave-uniform operands -- down this path, 16 F NE K bytes per 64-frame wave.
+PEAK_SMEM_BYTES_PER_CYCLE_PER_CU = 3.27
+NUM_CUS = 256
+CLOCK_GHZ = 2.4
+
+
+def estep_scalar_bytes(F, T, D, K):
+    """Bytes of model rows the register-form E-step pulls through the scalar cache per launch:
+    every wave (64 frames) reads the whole model of its frequency."""
+    return 16.0 * (D * (D + 1) // 2) * K * F * -(-T // 64)
 
 
 def stft_bin_bytes(F, T, D):
