@@ -473,16 +473,23 @@ def em_loop_entry(prof, steps, iterations, F, T, D, K, roofline):
     size = dict(F=F, T=T, D=D, K=K, taps=1, N=0)
     flops = sum(roofline.kernel_work(n, **size)['flops'] for n in ('em_estep', 'em_mstep', 'em_chol'))
     sec = ms_iter * 1e-3
-    # the E-step alone against the roof that binds it: the scalar data cache (its model rows are
-    # wave-uniform s_load operands; ceiling measured by tools/micro/smem_bench.hip)
+    # the E-step alone against the roof that binds it: VALU issue (a wave64 f64 instruction
+    # holds its SIMD for 4 cycles; tools/micro/valu_f64_bench.hip).  Priced at the NOMINAL
+    # 2.4 GHz; under f64 load the clock settles near 2.05 GHz (profiles/r03_valu_f64_bench.txt),
+    # so the fraction of the issue slots the silicon really had is ~1.17 x this.  The scalar
+    # cache the model rows come through is reported beside it; it does not bind
+    # (experiment 11).
     estep = None
     if 'em_estep' in prof and D in (4, 10, 12, 20, 24) and 2 <= K <= 6:
         e_sec = prof['em_estep']['ms'] / prof['em_estep']['calls'] * 1e-3
         rate = roofline.estep_scalar_bytes(F, T, D, K) / e_sec / roofline.NUM_CUS / (roofline.CLOCK_GHZ * 1e9)
-        estep = {'scalar_cache_bytes_per_launch': roofline.estep_scalar_bytes(F, T, D, K),
-                 'bytes_per_cycle_per_cu': rate,
-                 'measured_ceiling': roofline.PEAK_SMEM_BYTES_PER_CYCLE_PER_CU,
-                 'scalar_cache_frac': rate / roofline.PEAK_SMEM_BYTES_PER_CYCLE_PER_CU,
+        instr = roofline.estep_valu_instructions(F, T, D, K)
+        issue_sec = instr * roofline.VALU_F64_ISSUE_CYCLES / roofline.NUM_SIMDS / (roofline.CLOCK_GHZ * 1e9)
+        estep = {'bound': 'valu_issue',
+                 'walk_valu_instructions_per_launch': instr,
+                 'valu_issue_frac_at_nominal_clock': issue_sec / e_sec,
+                 'scalar_cache_bytes_per_launch': roofline.estep_scalar_bytes(F, T, D, K),
+                 'scalar_cache_frac_of_measured_ceiling': rate / roofline.PEAK_SMEM_BYTES_PER_CYCLE_PER_CU,
                  'valu_f64_frac': roofline.kernel_work('em_estep', **size)['flops'] / e_sec / 1e12
                  / roofline.PEAK_F64_TFLOPS}
     return {

@@ -17,16 +17,32 @@ PEAK_F64_TFLOPS = 78.6
 # (tools/micro/smem_bench.hip, profiles/r03_smem_bench.txt: 16 waves per CU streaming 64-byte
 # lines that hit the cache, four requests per wait: 122.7 loads / us / CU = 3.27 bytes per cycle
 # per CU at 2.4 GHz; one request per wait: 2.67).  The register-form E-step takes its model
-# rows -- wave-uniform operands -- down this path, 16 F NE K bytes per 64-frame wave.
+# rows -- wave-uniform operands -- down this path, 16 F NE K bytes per 64-frame wave.  It is
+# NOT what binds that kernel (with the scalar loads removed it runs 10 % faster, no more;
+# DESIGN.md section 8, experiment 11): reported for completeness.
 PEAK_SMEM_BYTES_PER_CYCLE_PER_CU = 3.27
 NUM_CUS = 256
+NUM_SIMDS = 1024
 CLOCK_GHZ = 2.4
+# VALU issue: a wave64 f64 instruction (v_fma_f64 / v_mul_f64 / v_add_f64, VGPR or SGPR
+# operands alike) occupies its SIMD for 4 cycles -- MEASURED 4.3 with two or more waves per
+# SIMD, 5.2 with one (tools/micro/valu_f64_bench.hip, profiles/r03_valu_f64_bench.txt), at a
+# shader clock that settles at 1.9 - 2.3 GHz under f64 load, not the nominal 2.4.
+VALU_F64_ISSUE_CYCLES = 4.0
 
 
 def estep_scalar_bytes(F, T, D, K):
     """Bytes of model rows the register-form E-step pulls through the scalar cache per launch:
     every wave (64 frames) reads the whole model of its frequency."""
     return 16.0 * (D * (D + 1) // 2) * K * F * -(-T // 64)
+
+
+def estep_valu_instructions(F, T, D, K):
+    """f64 VALU instructions of the triangle walk of the register-form E-step per launch
+    (wave64 instructions): per packed entry 4 for Re / Im (y_d1 conj y_d2) and 2 K for the K
+    quadratic forms, for every 64-frame wave.  The softmax epilogue (log, exp, division per
+    class and frame, ~10 % more at D = 24) is not counted."""
+    return (D * (D + 1) // 2) * (4.0 + 2.0 * K) * F * -(-T // 64)
 
 
 def stft_bin_bytes(F, T, D):
