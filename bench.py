@@ -485,7 +485,7 @@ def em_loop_entry(prof, steps, iterations, F, T, D, K, roofline):
         rate = roofline.estep_scalar_bytes(F, T, D, K) / e_sec / roofline.NUM_CUS / (roofline.CLOCK_GHZ * 1e9)
         instr = roofline.estep_valu_instructions(F, T, D, K)
         issue_sec = instr * roofline.VALU_F64_ISSUE_CYCLES / roofline.NUM_SIMDS / (roofline.CLOCK_GHZ * 1e9)
-        estep = {'bound': 'valu_issue',
+        estep = {'bound': 'valu_issue' if issue_sec / e_sec >= 0.3 else 'latency',
                  'walk_valu_instructions_per_launch': instr,
                  'valu_issue_frac_at_nominal_clock': issue_sec / e_sec,
                  'scalar_cache_bytes_per_launch': roofline.estep_scalar_bytes(F, T, D, K),
