@@ -334,12 +334,10 @@ __global__ __launch_bounds__(256) void em_estep_reg_kernel(EmArgs a, const cplx 
         if (a.masked) v[k] *= (valid && a.act[(int64_t)k * a.act_stride + tc]) ? 1.0 : 0.0;
         ssum += v[k];
     }
-    // one division and K products instead of K divisions (a twelfth of the epilogue, which
-    // is a fifth of this kernel's instructions); <= 1 ulp from v / ssum
-    const double rsum = 1.0 / fmax(ssum, GSS_TINY);
+    ssum = fmax(ssum, GSS_TINY);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        double gam = v[k] * rsum;
+        double gam = v[k] / ssum;
         if (a.aff_eps != 0.0) gam = fmin(fmax(gam, a.aff_eps), 1.0 - a.aff_eps);
         if (MODE == MODE_PREDICT) {
             if (valid) a.gamma[((int64_t)f * K + k) * T + t] = gam;
