@@ -178,7 +178,11 @@ int gss_mvdr_souden_ref(gss_ctx *ctx, const gss_cplx *Y_dev, int F, int64_t T, i
  * pipeline); synchronises the stream.  -1: a per-channel SNR was not finite -- pb_bss
  * get_optimal_reference_channel asserts np.all(np.isfinite(SNR)) and the reference
  * aborts the utterance with an AssertionError; here Xhat is filled with NaN and the host
- * raises.  INT32_MIN: no MVDR has run yet. */
+ * raises.  <= -2 (after gss_gev or the fused pipeline with the GEV beamformer): the noise
+ * PSD matrix of frequency -2 - value is not positive definite -- scipy.linalg.eigh inside
+ * pb_bss get_gev_vector raises numpy.linalg.LinAlgError there and the reference aborts the
+ * utterance; Xhat is NaN and the host raises the same.  0 after a successful GEV run.
+ * INT32_MIN: no beamformer has run yet. */
 int gss_last_ref_channel(gss_ctx *ctx, int32_t *ref_channel_host);
 
 /* Number of pivots the WPE solve of the last gss_wpe / fused call on this context zeroed

@@ -278,8 +278,10 @@ __global__ __launch_bounds__(64) void mvdr_solve_kernel(
 // Hermitian eigensolvers do (w^H Phi_N w = 1; the phase is arbitrary, as upstream).
 //   Phi_N = L L^H,  C = L^-1 Phi_X L^-H,  C u = lambda_max u,  w = L^-H u
 // One wave per frequency; w is written to column 0 of W so that mvdr_apply (with
-// ref = 0) does the BAN and the filtering.  A Phi_N that is not positive definite
-// yields NaN (the reference raises LinAlgError there).
+// ref = 0) does the BAN and the filtering.  A Phi_N that is not positive definite makes
+// scipy.linalg.eigh -- and with it the reference -- raise LinAlgError: the frequency is
+// recorded (ref[0] = -2, ref[1] = the lowest such frequency; the host presets 0 and a
+// large number), mvdr_apply fills Xhat with NaN and the host raises.
 __global__ __launch_bounds__(64) void gev_solve_kernel(const cplx *__restrict__ part,
                                                        const double *__restrict__ msum, int nch,
                                                        int D, cplx *__restrict__ Phi,
@@ -293,7 +295,6 @@ __global__ __launch_bounds__(64) void gev_solve_kernel(const cplx *__restrict__ 
     cplx *JV = JA + m * m;                         // m * m : eigenvectors
     cplx *Tm = JV + m * m;                         // m * m : Linv Phi_X
     const int f = blockIdx.x, lane = threadIdx.x;
-    if (f == 0 && lane == 0) ref[0] = 0;
 
     const double dx = fmax(msum[f * 2], 1e-10), dn = fmax(msum[f * 2 + 1], 1e-10);
     cplx *PhiX = Phi + (int64_t)f * 2 * D * D;
@@ -333,6 +334,10 @@ __global__ __launch_bounds__(64) void gev_solve_kernel(const cplx *__restrict__ 
     cplx *Wf = W + (int64_t)f * D * D;
     if (!cholesky_lower_wave(Ln, D, m, lane)) {
         for (int idx = lane; idx < D * D; idx += 64) Wf[idx] = c_make(NAN, NAN);
+        if (lane == 0) {
+            atomicMin(&ref[0], -2);
+            atomicMin(&ref[1], f);
+        }
         return;
     }
     invert_lower_wave(Ln, D, m, lane);          // Ln = L^-1 (lower)
@@ -472,12 +477,14 @@ __global__ __launch_bounds__(256) void mvdr_apply_kernel(
     const int f = blockIdx.y, tid = threadIdx.x;
     const int r = ref[0];
     if (blockIdx.x == 0 && f == 0 && tid == 0) {
-        if (ref_out) ref_out[0] = r;
-        if (status) __hip_atomic_store(status, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // -1: non-finite SNR (MVDR); -2 - f: Phi_N of frequency f not positive definite (GEV)
+        const int code = r == -2 ? -2 - ref[1] : r;
+        if (ref_out) ref_out[0] = code;
+        if (status) __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const int64_t c0 = (int64_t)blockIdx.x * chunk_frames;
     const int64_t c1 = c0 + chunk_frames < T ? c0 + chunk_frames : T;
-    if (r < 0) {   // non-finite SNR: the reference raises, nothing meaningful to write
+    if (r < 0) {   // the reference raises (see above), nothing meaningful to write
         const double qnan = __longlong_as_double(0x7ff8000000000000LL);
         for (int64_t t = c0 + tid; t < c1; t += blockDim.x) Xhat[t * F + f] = c_make(qnan, qnan);
         return;
@@ -591,6 +598,8 @@ int mvdr_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double 
             GSS_HIP_CHECK(ctx, hipFuncSetAttribute(
                                    reinterpret_cast<const void *>(gev_solve_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GSS_HIP_CHECK(ctx, hipMemsetAsync(ref, 0, sizeof(int32_t), ctx->stream));
+        GSS_HIP_CHECK(ctx, hipMemsetAsync(ref + 1, 0x7f, sizeof(int32_t), ctx->stream));
         hipLaunchKernelGGL(gev_solve_kernel, dim3(F), dim3(64), lds, ctx->stream, part, msum, nch,
                            D, Phi, W, ref);
         GSS_LAUNCH_CHECK(ctx, "gev_solve_kernel");

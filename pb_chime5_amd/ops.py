@@ -215,12 +215,24 @@ def _mask_to_device_ft(ctx, mask, T, F):
     return ctx.to_device(m)
 
 
-def _check_ref_channel(ctx):
-    """pb_bss get_optimal_reference_channel: ``assert np.all(np.isfinite(SNR)), SNR`` --
-    the reference aborts the utterance; the device reports it as reference channel -1."""
-    ref = ctx.last_ref_channel()
+def _raise_for_ref_channel(ref, name=None):
+    """The beamformer's status word (gss_last_ref_channel) as the exception the reference
+    raises.  -1: pb_bss get_optimal_reference_channel ``assert np.all(np.isfinite(SNR)), SNR``;
+    <= -2: pb_bss get_gev_vector re-raises scipy.linalg.eigh's LinAlgError ("Error for
+    frequency f ...") when the noise PSD matrix of a frequency is not positive definite."""
+    prefix = f'{name}: ' if name is not None else ''
     if ref == -1:       # (not an `assert` statement: those vanish under python -O)
-        raise AssertionError('get_optimal_reference_channel: the SNR is not finite')
+        raise AssertionError(f'{prefix}get_optimal_reference_channel: the SNR is not finite')
+    if -2 - (1 << 24) < ref <= -2:
+        raise np.linalg.LinAlgError(f'{prefix}Error for frequency {-2 - ref}: the noise PSD '
+                                    'matrix is not positive definite (get_gev_vector)')
+
+
+def _check_ref_channel(ctx):
+    """Raises what the reference raises for the last beamformer run on ``ctx``; returns the
+    reference channel otherwise."""
+    ref = ctx.last_ref_channel()
+    _raise_for_ref_channel(ref)
     return ref
 
 
@@ -252,7 +264,9 @@ def mvdr_souden_from_masks(Y, X_mask, N_mask, ban=False, *, ref_channel=None,
 
 def gev_from_masks(Y, X_mask, N_mask, ban=True, *, ctx=None):
     """beamform_gev_from_masks: Y (D,T,F), 2-D masks (T,F) -> X_hat (T,F).  The phase
-    of a generalised eigenvector is arbitrary (upstream too); magnitudes are defined."""
+    of a generalised eigenvector is arbitrary (upstream too); magnitudes are defined.
+    Raises numpy.linalg.LinAlgError when the noise PSD matrix of a frequency is not positive
+    definite, like scipy.linalg.eigh inside pb_bss get_gev_vector."""
     ctx = ctx or default_context()
     Y_d, (D, T, F) = _obs_to_device_ftd(ctx, Y)
     mx = _mask_to_device_ft(ctx, X_mask, T, F)
@@ -260,6 +274,7 @@ def gev_from_masks(Y, X_mask, N_mask, ban=True, *, ctx=None):
     X_d = ctx.empty(16 * F * T)
     ctx._check(ctx.lib.gss_gev(ctx.handle, c_void_p(Y_d.ptr), F, T, D, c_void_p(mx.ptr),
                                c_void_p(mn.ptr), int(bool(ban)), c_void_p(X_d.ptr)), 'gss_gev')
+    _check_ref_channel(ctx)
     return ctx.to_host(X_d, (T, F), np.complex128)
 
 
@@ -331,7 +346,7 @@ class ResidentUtterance:
 
     def result(self):
         x_hat = self.ctx.to_host(self.out_d, (self.n_out,), np.float64)
-        if self.params.bf == _BF_CODES['mvdrSouden_ban']:
+        if self.params.bf in (_BF_CODES['mvdrSouden_ban'], _BF_CODES['gev_ban']):
             _check_ref_channel(self.ctx)
         return x_hat
 
@@ -405,12 +420,12 @@ class UtterancePipeline:
     def pop(self):
         tag, slot, n_out = self._pending.popleft()
         x_hat = self.slots[slot].to_host(self._bufs[slot]['out'], (n_out,), np.float64)
-        if self.params.bf == _BF_CODES['mvdrSouden_ban'] and self.slots[slot].last_ref_channel() == -1:
-            # pb_bss get_optimal_reference_channel: assert np.all(np.isfinite(SNR)).  Raised
-            # explicitly (an `assert` statement disappears under python -O and NaN audio would
-            # be written silently); `tag` may be a whole example dict: name it by its id.
+        if self.params.bf in (_BF_CODES['mvdrSouden_ban'], _BF_CODES['gev_ban']):
+            # what the reference raises for this utterance (raised explicitly: an `assert`
+            # statement disappears under python -O and NaN audio would be written silently);
+            # `tag` may be a whole example dict: name it by its id.
             name = tag.get('example_id', '?') if isinstance(tag, dict) else tag
-            raise AssertionError(f'{name}: get_optimal_reference_channel: the SNR is not finite')
+            _raise_for_ref_channel(self.slots[slot].last_ref_channel(), name)
         return tag, x_hat
 
     def close(self):

@@ -1,5 +1,6 @@
 """Test infrastructure: the beamformer formulas of pb_bss (call sites
-/root/reference/pb_chime5/speech_enhancement/beamforming_wrapper.py:49-75) evaluated in 80-bit
+/root/reference/pb_chime5/speech_enhancement/beamforming_wrapper.py:49-75) and the WPE iteration
+of nara_wpe (call site core.py:48-58) evaluated in 80-bit
 extended precision, one frequency at a time -- the referee for frequency bins where the
 float64 evaluation of those formulas (the reference's, hence the oracle's) is itself decided by
 rounding: with a nearly singular noise PSD matrix np.linalg.solve loses cond(Phi_N) * eps and
@@ -88,6 +89,47 @@ def gev_ban_output(Y, target_mask, distortion_mask):
     v = v / np.sqrt(np.real(np.vdot(v, cov_n @ v)))
     w = ban(v, cov_n)
     return (w.conj() @ Y.astype(CLD)).astype(np.complex128)
+
+
+def cholesky_solve(R, P):
+    """Hermitian positive definite solve in extended precision, one refinement step."""
+    n = R.shape[0]
+    L = np.zeros_like(R)
+    for j in range(n):
+        d = np.sqrt((R[j, j] - np.sum(np.abs(L[j, :j]) ** 2)).real)
+        L[j, j] = d
+        L[j + 1:, j] = (R[j + 1:, j] - L[j + 1:, :j] @ L[j, :j].conj()) / d
+    LH = L.conj().T
+
+    def solve_(B):
+        Z = np.zeros_like(B)
+        for j in range(n):
+            Z[j] = (B[j] - L[j, :j] @ Z[:j]) / L[j, j]
+        G = np.zeros_like(B)
+        for j in range(n - 1, -1, -1):
+            G[j] = (Z[j] - LH[j, j + 1:] @ G[j + 1:]) / LH[j, j]
+        return G
+
+    G = solve_(P)
+    return G + solve_(P - R @ G)
+
+
+def wpe(Y, Y_tilde, iterations):
+    """nara_wpe.wpe.wpe_v6 (statistics_mode='full', psd_context=0; call site
+    /root/reference/pb_chime5/core.py:48-58) for one frequency in extended precision:
+    Y (D, T) complex128, Y_tilde (taps D, T) its delayed stack -> list of X after every
+    iteration, rounded to complex128."""
+    Yl, Yt = Y.astype(CLD), Y_tilde.astype(CLD)
+    X = Yl.copy()
+    out = []
+    for _ in range(iterations):
+        power = np.mean(X.real ** 2 + X.imag ** 2, axis=0)
+        w = 1 / np.maximum(power, LD(1e-10) * np.max(power))
+        Yw = Yt * w[None, :]
+        G = cholesky_solve(Yw @ Yt.conj().T, Yw @ Yl.conj().T)
+        X = Yl - G.conj().T @ Yt
+        out.append(X.astype(np.complex128))
+    return out
 
 
 def _bin_job(job):

@@ -25,56 +25,20 @@ from pathlib import Path
 import numpy as np
 
 REPO = Path(__file__).resolve().parents[2]
-for p in (str(REPO), str(REPO / 'oracle')):
+for p in (str(REPO), str(REPO / 'oracle'), str(REPO / 'tests')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
 BINS = (169, 40, 300)        # 169: the worst bin of the end-to-end test in rounds 1-2
 TAPS, DELAY = 10, 2
-LD, CLD = np.longdouble, np.clongdouble
-
-
-def cholesky_solve_ld(R, P):
-    """Hermitian positive definite solve in extended precision, one refinement step."""
-    n = R.shape[0]
-    L = np.zeros_like(R)
-    for j in range(n):
-        d = np.sqrt((R[j, j] - np.sum(np.abs(L[j, :j]) ** 2)).real)
-        L[j, j] = d
-        L[j + 1:, j] = (R[j + 1:, j] - L[j + 1:, :j] @ L[j, :j].conj()) / d
-    LH = L.conj().T
-
-    def solve(B):
-        Z = np.zeros_like(B)
-        for j in range(n):
-            Z[j] = (B[j] - L[j, :j] @ Z[:j]) / L[j, j]
-        G = np.zeros_like(B)
-        for j in range(n - 1, -1, -1):
-            G[j] = (Z[j] - LH[j, j + 1:] @ G[j + 1:]) / LH[j, j]
-        return G
-
-    G = solve(P)
-    return G + solve(P - R @ G)
 
 
 def wpe_ld(Y, iterations):
-    """wpe_v6 (statistics_mode='full', psd_context=0) in extended precision.
-    Y (D, T) complex128 -> list of X after every iteration, complex128."""
+    """Extended-precision WPE of one frequency (tests/ext_precision.py): Y (D, T) complex128 ->
+    list of X after every iteration, complex128."""
+    import ext_precision
     import gss_oracle as oracle
-    Yl = Y.astype(CLD)
-    Yt = oracle.build_y_tilde(Y, TAPS, DELAY).astype(CLD)
-    X = Yl.copy()
-    out = []
-    for _ in range(iterations):
-        power = np.mean(X.real ** 2 + X.imag ** 2, axis=0)
-        w = 1 / np.maximum(power, LD(1e-10) * np.max(power))
-        Yw = Yt * w[None, :]
-        R = Yw @ Yt.conj().T
-        P = Yw @ Yl.conj().T
-        G = cholesky_solve_ld(R, P)
-        X = Yl - G.conj().T @ Yt
-        out.append(X.astype(np.complex128))
-    return out
+    return ext_precision.wpe(Y, oracle.build_y_tilde(Y, TAPS, DELAY), iterations)
 
 
 def _one(args):

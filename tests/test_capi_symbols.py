@@ -86,3 +86,19 @@ def test_abi_revision_is_checked_on_load(tmp_path):
     assert lib.gss_abi_version() == _capi.GSS_ABI_VERSION
     text = (REPO / 'include' / 'gss_hip.h').read_text()
     assert f'#define GSS_ABI_VERSION {_capi.GSS_ABI_VERSION}' in text
+
+
+def test_beamformer_status_word_maps_to_the_reference_exceptions():
+    """gss_last_ref_channel: -1 -> AssertionError (non-finite SNR, pb_bss
+    get_optimal_reference_channel), -2 - f -> numpy.linalg.LinAlgError naming frequency f
+    (scipy.linalg.eigh in get_gev_vector); channels and the "nothing ran yet" word pass."""
+    import numpy as np
+    from pb_chime5_amd import ops
+    for ok in (0, 3, 23, -2 ** 31):
+        ops._raise_for_ref_channel(ok)
+    with pytest.raises(AssertionError, match='S02_U01: .*SNR is not finite'):
+        ops._raise_for_ref_channel(-1, 'S02_U01')
+    with pytest.raises(np.linalg.LinAlgError, match='frequency 17'):
+        ops._raise_for_ref_channel(-2 - 17)
+    with pytest.raises(np.linalg.LinAlgError, match='frequency 0'):
+        ops._raise_for_ref_channel(-2)

@@ -307,6 +307,28 @@ def test_cacgmm_matches_oracle(gpu_ctx, D, T, F, K, iters, post):
     assert np.max(np.abs(got.sum(axis=0) - 1)) < 1e-12 or post == 0
 
 
+def test_cacgmm_class_with_fewer_frames_than_channels(gpu_ctx):
+    """Found by the wide fuzz sweep (GSS_FUZZ_SEED=202 GSS_FUZZ_WIDE=1, case 220, bin 43): 29
+    channels, 110 frames, and after the first iteration the noise class is left with five
+    frames' worth of posterior mass.  Its covariance has a continuum of eigenvalues from 1e-13
+    to 1 of the largest and the model's 1e-10 floor cuts through the middle of it.  The
+    Jacobi eigensolver judged convergence by the off-diagonal mass of the WHOLE matrix and
+    stopped while the directions on either side of the cut were still mixed: posteriors
+    7e-4 (two iterations) and 1.6e-2 (three) from the oracle, which an independent float64
+    implementation matches to 2e-6.  It now converges pair by pair (jacobi.h)."""
+    from pb_chime5_amd import ops, synthetic
+    u = synthetic.tiny(seed=5220, num_channels=29, num_samples=27357, num_speakers=3,
+                       context=757, noise=5e-2)
+    Y = oracle.stft(u.obs)
+    act = oracle.activity_time_to_frequency(np.asarray(u.activity_array), 1024, 256, True,
+                                            stft_pad=True)[:, :Y.shape[1]]
+    Of = np.ascontiguousarray(Y[..., 41:46])          # bin 43 and its neighbours
+    for iterations, post in ((2, 0), (2, 2), (3, 1)):
+        got = ops.cacgmm_posteriors(Of, act, iterations, post, ctx=gpu_ctx)
+        want = oracle.gss_block_batched(Of, act, iterations=iterations, iterations_post=post)
+        assert np.max(np.abs(got - want)) < 1e-5, (iterations, post, np.max(np.abs(got - want)))
+
+
 def test_cacgmm_short_activity_rank_deficient_class(gpu_ctx):
     """A speaker active for fewer frames than channels: its covariance is rank
     deficient and the 1e-10 eigenvalue floor is what the posteriors hinge on."""
@@ -511,6 +533,28 @@ def test_gev_matches_oracle_up_to_phase(gpu_ctx, D, T, F, ban):
         # eigensolver normalisation: w^H Phi_N w = 1  <=>  mean_t n |w^H y|^2 ... checked via
         # the oracle's vector: same magnitudes means same scale
         assert np.all(np.isfinite(got))
+
+
+def test_gev_noise_psd_not_positive_definite_raises_like_reference(gpu_ctx):
+    """A frequency whose distortion mask is all zero has Phi_N = 0: scipy.linalg.eigh inside
+    pb_bss get_gev_vector raises LinAlgError and the reference aborts the utterance.  Same
+    exception type here, naming the (lowest) offending frequency; a later well-posed call on
+    the same context is not affected."""
+    from pb_chime5_amd.speech_enhancement.beamforming_wrapper import beamform_gev_from_masks
+    rng = np.random.default_rng(11)
+    D, T, F = 5, 90, 7
+    Y, act = _scene(rng, D, T, F, 3)
+    xm = rng.uniform(0.1, 1.0, size=(T, F))
+    nm = 1 - xm
+    bad_x, bad_n = xm.copy(), nm.copy()
+    bad_n[:, 4] = 0.0
+    bad_n[:, 2] = 0.0
+    with pytest.raises(np.linalg.LinAlgError):
+        oracle.beamform_gev_from_masks(Y, bad_x, bad_n, ban=True)
+    with pytest.raises(np.linalg.LinAlgError, match='frequency 2'):
+        beamform_gev_from_masks(Y, bad_x, bad_n, ban=True, ctx=gpu_ctx)
+    got = beamform_gev_from_masks(Y, xm, nm, ban=True, ctx=gpu_ctx)
+    assert rel_err(np.abs(got), np.abs(oracle.beamform_gev_from_masks(Y, xm, nm, ban=True))) < 1e-8
 
 
 def test_gev_in_the_fused_pipeline(gpu_ctx):
