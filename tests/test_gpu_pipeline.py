@@ -569,7 +569,8 @@ def _oracle_snr(cov_x, cov_n):
     return num / np.maximum(den, 1e-10)
 
 
-def _check_ref_channel_or_tie(gpu_ctx, det, wdet, tag, mismatches, well_conditioned=None):
+def _check_ref_channel_or_tie(gpu_ctx, det, wdet, tag, mismatches, well_conditioned=None,
+                              postfilter=None):
     """The reference channel is one integer and must equal the oracle's.  A different
     channel is tolerated only when it is CERTIFIED that the oracle's own answer is not
     defined to that precision:
@@ -595,10 +596,14 @@ def _check_ref_channel_or_tie(gpu_ctx, det, wdet, tag, mismatches, well_conditio
     mismatches.append(dict(tag=tag, gpu=g, oracle=o, gap=float(gap), last_bit_move=float(moved),
                            cond_max=float(cond.max())))
     assert gap < 1e-9 or moved > gap or not np.isfinite(moved), (tag, g, o, gap, moved, cond.max())
-    if well_conditioned is not None:
+    if well_conditioned is not None and gap >= 1e-9:
+        # (an exact tie -- two classes the EM cannot tell apart end with equal masks,
+        # Phi_X = Phi_N and the same SNR on every channel -- is a tie on any scene)
         assert not well_conditioned, (tag, 'reference channel differs on a well-conditioned scene')
     X_forced = ops.mvdr_souden_from_masks(det['Obs'], det['target_mask'], det['distortion_mask'],
                                           ban=True, ref_channel=o, ctx=gpu_ctx)
+    if postfilter == 'mask_mul':
+        X_forced = X_forced * det['target_mask']
     good = cond < 1e8
     assert good.any(), tag
     assert rel_err(np.abs(X_forced[:, good]), np.abs(wdet['X_hat'][:, good])) < TOL_STFT_MAG, tag
@@ -890,20 +895,24 @@ def _fuzz_case(gpu_ctx, ref_mismatches, case, D, K, N, ctx_s, kw, wide=False):
     try:
         got, det = ops.enhance_observation(u.obs, u.activity_array, u.target_index, ctx_s, ctx_s,
                                            debug=True, ctx=gpu_ctx, **kw)
-    except np.linalg.LinAlgError:
-        raised.append('gpu')
+    except (np.linalg.LinAlgError, AssertionError) as e:
+        raised.append('gpu ' + type(e).__name__)
     try:
         want, wdet = oracle.enhance_observation(u.obs, u.activity_array, u.target_index, u.ex,
                                                 return_details=True,
                                                 gss_fn=oracle.gss_block_batched, **kw)
-    except np.linalg.LinAlgError:
-        raised.append('oracle')
+    except (np.linalg.LinAlgError, AssertionError) as e:
+        raised.append('oracle ' + type(e).__name__)
     if raised:
-        # GEV with a noise PSD matrix that is not positive definite: the reference aborts the
-        # utterance.  Singular to rounding, the two Cholesky factorisations need not agree on
-        # which side of zero a pivot falls, so one of them raising alone is not an error.
-        assert bf == 'gev_ban', (tag, raised)
-        return 'raises: ' + '+'.join(raised)
+        # The reference aborts the utterance: GEV with a noise PSD matrix that is not positive
+        # definite (LinAlgError from scipy.linalg.eigh), MVDR with an SNR that is not finite
+        # (the assert in get_optimal_reference_channel).  Both are decided by the rounding of
+        # a matrix that is singular to working precision, so one side raising alone is not an
+        # error -- but it has to be the exception of that beamformer.
+        kinds = {r.split()[1] for r in raised}
+        assert kinds == {'LinAlgError' if bf == 'gev_ban' else 'AssertionError'} and \
+            bf in ('gev_ban', 'mvdrSouden_ban'), (tag, raised)
+        return 'raises: ' + ', '.join(raised)
     assert got.shape == want.shape, tag
     assert np.array_equal(det['acitivity_freq'], wdet['activity_freq'][:, :det['Obs'].shape[1]]), tag
     det['obs_in'] = u.obs
@@ -911,6 +920,28 @@ def _fuzz_case(gpu_ctx, ref_mismatches, case, D, K, N, ctx_s, kw, wide=False):
         (tag, rel_err(det['Obs'], wdet['Obs']))
     if rel_err(det['Obs'], wdet['Obs']) >= 1e-6:
         return 'ill-conditioned WPE'    # both results rounding-decided: nothing downstream compares
+    # the masks: equal to 1e-6, or -- classes left with fewer effective frames than channels
+    # have a continuum of eigenvalues that the model's 1e-10 floor cuts through, and any two
+    # float64 implementations then disagree -- the GPU is no further from the oracle than 10 x
+    # the brute-force EM of tests/test_oracle_independent.py on the frequency that differs most
+    def per_bin(a, b):
+        return np.linalg.norm(a - b, axis=0) / np.maximum(np.linalg.norm(b, axis=0), 1e-300)
+    loud = np.linalg.norm(wdet['X_hat'], axis=0)
+    loud = loud > 1e-4 * loud.max()                    # bins that matter for the output
+    dmask = np.maximum(per_bin(det['target_mask'], wdet['target_mask']),
+                       per_bin(det['distortion_mask'], wdet['distortion_mask'])) * loud
+    if dmask.max() > 1e-6:
+        from test_oracle_independent import brute_force_guided_em
+        f = int(np.argmax(dmask))
+        act = wdet['activity_freq'][:, :wdet['Obs'].shape[1]]
+        Of = np.ascontiguousarray(wdet['Obs'][..., f:f + 1])
+        it, post = kw['bss_iterations'], kw['bss_iterations_post']
+        g = ops.cacgmm_posteriors(Of, act, it, post, ctx=gpu_ctx)[..., 0]
+        o = oracle.gss_block_batched(Of, act, iterations=it, iterations_post=post)[..., 0]
+        b = brute_force_guided_em(np.ascontiguousarray(Of[..., 0].T), act, it, post)
+        d_go, d_ob = np.max(np.abs(g - o)), np.max(np.abs(o - b))
+        assert d_go <= 10 * d_ob + 1e-8, (tag, "EM of frequency", f, d_go, d_ob)
+        return 'sensitive EM'
     if bf == 'mvdrSouden_ban':
         # bins with a nearly singular Phi_N are decided by rounding in the reference too
         cond = np.linalg.cond(wdet['cov_n'])
@@ -919,7 +950,8 @@ def _fuzz_case(gpu_ctx, ref_mismatches, case, D, K, N, ctx_s, kw, wide=False):
             return 'singular Phi_N'     # one point source on many microphones (K = 2)
         assert good.mean() > 0.5, tag
         if _check_ref_channel_or_tie(gpu_ctx, det, wdet, tag, ref_mismatches,
-                                     well_conditioned=bool(cond.max() < 1e8)):
+                                     well_conditioned=bool(cond.max() < 1e8),
+                                     postfilter=kw['postfilter']):
             if rel_err(np.abs(det['X_hat'][:, good]), np.abs(wdet['X_hat'][:, good])) >= TOL_STFT_MAG:
                 # blind_analytic_normalization's einsum loses cond^2 eps in the reference (see
                 # _beamformer_all_bins_with_referee): the frequencies that differ go to the
