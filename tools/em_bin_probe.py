@@ -22,19 +22,17 @@ def main():
         g = ops.cacgmm_posteriors(d['Of'], d['act'], int(sys.argv[4]), int(sys.argv[5]))[..., 0]
         np.save(sys.argv[6], g)
         return
+    import fuzz_params
     want_case, f = int(sys.argv[1]), int(sys.argv[2])
-    rng = np.random.default_rng(int(os.environ.get('GSS_FUZZ_SEED', 2024)))
-    wide = bool(os.environ.get('GSS_FUZZ_WIDE'))
-    for case in range(want_case + 1):
-        D = int(rng.integers(2, 30)); K = int(rng.integers(2, 13) if wide else rng.integers(3, 7))
-        N = int(rng.integers(9000, 36000)); ctx_s = int(rng.integers(0, 3000))
-        rng.integers(1, 4); rng.integers(1, 4); rng.integers(1, 3)
-        rng.integers(1, 5); rng.integers(0, 3)
-        rng.integers(0, 4 if wide else 3); rng.integers(0, 2); rng.integers(0, 4)
+    seed, _, wide = fuzz_params.from_environment()
+    case, D, K, N, ctx_s, kw = [c for c in fuzz_params.fuzz_cases(seed, want_case + 1, wide)
+                                if c[0] == want_case][0]
+    size, shift = kw.get('stft_size', 1024), kw.get('stft_shift', 256)
+    fading = kw.get('stft_fading', True)
     u = synthetic.tiny(seed=5000 + case, num_channels=D, num_samples=N, num_speakers=K - 1,
                        context=ctx_s, noise=5e-2)
-    Y = oracle.stft(u.obs)
-    act = oracle.activity_time_to_frequency(np.asarray(u.activity_array), 1024, 256, True,
+    Y = oracle.stft(u.obs, size, shift, fading=fading)
+    act = oracle.activity_time_to_frequency(np.asarray(u.activity_array), size, shift, fading,
                                             stft_pad=True)[:, :Y.shape[1]]
     Of = np.ascontiguousarray(Y[..., f:f + 1])
     out = R / 'gpurun_out'

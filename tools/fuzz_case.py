@@ -18,21 +18,17 @@ def main():
     import ext_precision
     import gss_oracle as oracle
     from pb_chime5_amd import ops, synthetic
+    import fuzz_params
     want_case = int(sys.argv[1])
-    rng = np.random.default_rng(int(os.environ.get('GSS_FUZZ_SEED', 2024)))
-    wide = bool(os.environ.get('GSS_FUZZ_WIDE'))
-    for case in range(want_case + 1):
-        D = int(rng.integers(2, 30)); K = int(rng.integers(2, 13) if wide else rng.integers(3, 7))
-        N = int(rng.integers(9000, 36000)); ctx_s = int(rng.integers(0, 3000))
-        taps = int(rng.integers(1, 4)); delay = int(rng.integers(1, 4)); wit = int(rng.integers(1, 3))
-        bss = int(rng.integers(1, 5)); post = int(rng.integers(0, 3))
-        bf = ['mvdrSouden_ban', 'ch2', 'sum', 'gev_ban'][int(rng.integers(0, 4 if wide else 3))]
-        if bf == 'ch2' and D < 3:
-            bf = 'sum'
-        pf = [None, 'mask_mul'][int(rng.integers(0, 2))]
-        wpe = bool(rng.integers(0, 4) > 0)
-    kw = dict(wpe=wpe, wpe_taps=taps, wpe_delay=delay, wpe_iterations=wit, bss_iterations=bss,
-              bss_iterations_post=post, bf=bf, postfilter=pf)
+    seed, _, wide = fuzz_params.from_environment()
+    hit = [c for c in fuzz_params.fuzz_cases(seed, want_case + 1, wide) if c[0] == want_case]
+    assert hit, f'case {want_case} is not a runnable draw of seed {seed}'
+    case, D, K, N, ctx_s, kw = hit[0]
+    taps, delay, wit = kw['wpe_taps'], kw['wpe_delay'], kw['wpe_iterations']
+    bss, post, bf, pf, wpe = (kw['bss_iterations'], kw['bss_iterations_post'], kw['bf'],
+                              kw['postfilter'], kw['wpe'])
+    size, shift = kw.get('stft_size', 1024), kw.get('stft_shift', 256)
+    fading, psd_context = kw.get('stft_fading', True), kw.get('wpe_psd_context', 0)
     print(dict(case=case, D=D, K=K, N=N, ctx=ctx_s), kw)
     u = synthetic.tiny(seed=5000 + case, num_channels=D, num_samples=N, num_speakers=K - 1,
                        context=ctx_s, noise=5e-2)
@@ -46,12 +42,12 @@ def main():
     F = Xg.shape[-1]
     print('frames', Xg.shape[1], ' WPE output, GPU vs oracle:', n(Xg - Xo) / n(Xo))
     if wpe:
-        Y = oracle.stft(u.obs)
+        Y = oracle.stft(u.obs, size, shift, fading=fading)
         per = np.array([n(Xg[..., f] - Xo[..., f]) / n(Xo[..., f]) for f in range(F)])
         for f in np.argsort(per)[::-1][:4]:
             Yf = np.ascontiguousarray(Y[..., f])
             Yt = oracle.build_y_tilde(Yf, taps, delay)
-            Xt = ext_precision.wpe(Yf, Yt, wit)[-1]
+            Xt = ext_precision.wpe(Yf, Yt, wit)[-1]          # (psd_context = 0 only)
             cond = np.linalg.cond((Yt * oracle.get_power_inverse(Yf)) @ Yt.conj().T)
             print(f'  bin {f}: GPU-oracle {per[f]:.2e}  GPU-truth {n(Xg[..., f] - Xt) / n(Xt):.2e}  '
                   f'oracle-truth {n(Xo[..., f] - Xt) / n(Xt):.2e}  cond(R) {cond:.2e}')
