@@ -30,24 +30,28 @@ __device__ inline int jacobi_eigh_wave(cplx *A, cplx *V, int m, int lane, int ma
     int sweep = 0;
     bool last = false;
     for (; sweep < max_sweeps; ++sweep) {
-        // Convergence is judged PER PAIR, |a_ij|^2 against a_ii a_jj (the criterion that
-        // gives the small eigenvalues of a positive definite matrix their relative
-        // accuracy): a class covariance estimated from fewer frames than channels has a
-        // continuum of eigenvalues from 1e-13 to 1 of the largest, the 1e-10 floor of the
-        // model cuts through the middle of it, and an off-diagonal mass of 1e-10 of the
-        // whole -- converged by the global measure -- still mixes the directions on either
-        // side of that cut (posteriors off by 1e-3, wide fuzz seed 202 case 220).  Once the
-        // worst pair is below 1e-20 the (quadratically convergent) next sweep reaches the
-        // rounding floor.  A zero diagonal entry under a non-zero off-diagonal one (only
-        // with an indefinite input) counts as not converged.
+        // Convergence is judged PER PAIR, |a_ij| against the larger of |a_ii|, |a_jj| (the
+        // rotation angle it still stands for is |a_ij| / |a_ii - a_jj|): a class covariance
+        // estimated from fewer frames than channels has a continuum of eigenvalues from 1e-13
+        // to 1 of the largest, the 1e-10 floor of the model cuts through the middle of it, and
+        // an off-diagonal mass of 1e-10 of the WHOLE matrix -- where the former global measure
+        // let the last sweep start -- still mixes the directions on either side of that cut
+        // (posteriors off by 1e-3, wide fuzz seed 202 case 220).  Pairs that lie entirely
+        // within the rounding noise of the matrix (both diagonal entries below 1e-13 of the
+        // largest, far below that floor) never settle and are left alone.  Once the worst
+        // pair is below 1e-10 the (quadratically convergent) next sweep reaches the rounding
+        // floor.
+        double dmax = 0.0;
+        for (int i = lane; i < m; i += 64) dmax = fmax(dmax, fabs(A[i * m + i].x));
+        dmax = wave_max(dmax);
         double worst = 0.0;
         for (int i = grp; i < m; i += 4)
             for (int j = pr; j < m; j += 16) {
                 if (i == j) continue;
                 const double v = c_abs2(A[i * m + j]);
-                if (v == 0.0) continue;
-                const double dd = fabs(A[i * m + i].x * A[j * m + j].x);
-                worst = fmax(worst, dd > 0.0 ? v / dd : INFINITY);
+                const double mx = fmax(fabs(A[i * m + i].x), fabs(A[j * m + j].x));
+                if (v == 0.0 || mx <= 1e-13 * dmax) continue;
+                worst = fmax(worst, v / (mx * mx));
             }
         worst = wave_max(worst);
         if (last || worst <= 1e-30) break;
