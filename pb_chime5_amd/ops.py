@@ -59,6 +59,8 @@ def synthesis_window(analysis, shift):
 
 
 def _prepare_windows(ctx, size, shift, window=None):
+    # (the shift has to divide the window: nara_wpe's istft asserts it for its synthesis window,
+    # and the library keeps one (size, shift) pair of windows per context for both directions)
     a = analysis_window(size, window)
     s = synthesis_window(a, shift)
     ctx.set_windows(size, shift, a, s)
@@ -84,11 +86,15 @@ def stft(time_signal, size=1024, shift=256, *, window=None, fading=True, ctx=Non
     x = np.asarray(time_signal, dtype=np.float64)
     lead = x.shape[:-1]
     N = x.shape[-1]
-    x2 = np.ascontiguousarray(x.reshape(-1, N))
-    D = x2.shape[0]
+    D = int(np.prod(lead, dtype=np.int64)) if lead else 1
+    x2 = np.ascontiguousarray(x.reshape(D, N))
     _prepare_windows(ctx, size, shift, window)
     F = size // 2 + 1
     T = stft_frames(N, size, shift, fading)
+    if D == 0 or T == 0:
+        return np.zeros(lead + (T, F), np.complex128)
+    if N == 0:          # nothing but the fading pad: frames of zeros
+        return np.zeros(lead + (T, F), np.complex128)
     x_d = ctx.to_device(x2)
     Y_d = ctx.empty(16 * F * T * D)
     O_d = ctx.empty(16 * F * T * D)

@@ -65,6 +65,16 @@ def test_stft_leading_axes_and_shapes(gpu_ctx):
     assert ops.stft(np.zeros(80000), ctx=gpu_ctx).shape == (316, 513)
 
 
+def test_stft_of_an_empty_signal(gpu_ctx):
+    """pad=True always yields at least one frame; an empty signal gives frames of zeros (found by
+    tools/fuzz_stft.py: the host side tripped over the reshape)."""
+    from pb_chime5_amd import ops
+    for fading in (True, False):
+        want = oracle.stft(np.zeros((3, 0)), 512, 128, fading=fading)
+        got = ops.stft(np.zeros((3, 0)), 512, 128, fading=fading, ctx=gpu_ctx)
+        assert got.shape == want.shape and not got.any()
+
+
 @pytest.mark.parametrize('size,shift,T', [(1024, 256, 37), (1024, 256, 38), (64, 16, 131),
                                           (512, 128, 1), (512, 256, 20), (1000, 250, 33),
                                           (60, 20, 50)])
