@@ -383,6 +383,9 @@ extern "C" int gss_wpe(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T, int D,
     GSS_REQUIRE(ctx, taps >= 1 && delay >= 0 && iterations >= 0 && psd_context >= 0,
                 GSS_ERR_INVALID, "gss_wpe: taps=%d delay=%d iterations=%d psd_context=%d", taps,
                 delay, iterations, psd_context);
+    GSS_REQUIRE(ctx, (int64_t)F * T * D < (1LL << 31), GSS_ERR_UNSUPPORTED,
+                "F * T * D = %lld STFT bins: 2^31 or more are not supported (some kernels index "
+                "the tensor with 32 bits)", (long long)((int64_t)F * T * D));
     GSS_TRY(arena_reserve(ctx, wpe_workspace_bytes(F, T, D, taps, delay)));
     return wpe_run(ctx, reinterpret_cast<const cplx *>(Y), F, T, D, taps, delay, iterations,
                    psd_context, reinterpret_cast<cplx *>(X));
@@ -406,6 +409,9 @@ extern "C" int gss_cacgmm(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T, int
     GSS_REQUIRE(ctx, Y && act && gamma && F >= 1 && T >= 1, GSS_ERR_INVALID,
                 "gss_cacgmm: bad arguments");
     GSS_TRY(check_cacgmm_args(ctx, D, K, iterations, post));
+    GSS_REQUIRE(ctx, (int64_t)F * T * D < (1LL << 31), GSS_ERR_UNSUPPORTED,
+                "F * T * D = %lld STFT bins: 2^31 or more are not supported (some kernels index "
+                "the tensor with 32 bits)", (long long)((int64_t)F * T * D));
     GSS_TRY(arena_reserve(ctx, cacgmm_workspace_bytes(F, T, D, K)));
     return cacgmm_run(ctx, reinterpret_cast<const cplx *>(Y), F, T, D, act, T, K, iterations,
                       post, gamma);
@@ -430,6 +436,9 @@ extern "C" int gss_mvdr_souden(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T
                 "gss_mvdr_souden: bad arguments");
     // beamforming_wrapper.py:44: assert D < 30
     GSS_REQUIRE(ctx, D >= 1 && D < 30, GSS_ERR_INVALID, "assert D < 30 failed: D=%d", D);
+    GSS_REQUIRE(ctx, (int64_t)F * T * D < (1LL << 31), GSS_ERR_UNSUPPORTED,
+                "F * T * D = %lld STFT bins: 2^31 or more are not supported (some kernels index "
+                "the tensor with 32 bits)", (long long)((int64_t)F * T * D));
     GSS_TRY(arena_reserve(ctx, mvdr_workspace_bytes(F, T, D)));
     return mvdr_run(ctx, reinterpret_cast<const cplx *>(Y), F, T, D, mx, mn, ban,
                     reinterpret_cast<cplx *>(Xhat), ref);
@@ -444,6 +453,9 @@ extern "C" int gss_mvdr_souden_ref(gss_ctx *ctx, const gss_cplx *Y, int F, int64
     GSS_REQUIRE(ctx, D >= 1 && D < 30, GSS_ERR_INVALID, "assert D < 30 failed: D=%d", D);
     GSS_REQUIRE(ctx, ref_channel >= 0 && ref_channel < D, GSS_ERR_INVALID,
                 "ref_channel %d outside [0, %d)", ref_channel, D);
+    GSS_REQUIRE(ctx, (int64_t)F * T * D < (1LL << 31), GSS_ERR_UNSUPPORTED,
+                "F * T * D = %lld STFT bins: 2^31 or more are not supported (some kernels index "
+                "the tensor with 32 bits)", (long long)((int64_t)F * T * D));
     GSS_TRY(arena_reserve(ctx, mvdr_workspace_bytes(F, T, D)));
     return mvdr_run(ctx, reinterpret_cast<const cplx *>(Y), F, T, D, mx, mn, ban,
                     reinterpret_cast<cplx *>(Xhat), nullptr, /*gev=*/0, ref_channel);
@@ -471,6 +483,9 @@ extern "C" int gss_gev(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T, int D,
     GSS_REQUIRE(ctx, Y && mx && mn && Xhat && F >= 1 && T >= 1, GSS_ERR_INVALID,
                 "gss_gev: bad arguments");
     GSS_REQUIRE(ctx, D >= 1 && D < 30, GSS_ERR_INVALID, "assert D < 30 failed: D=%d", D);
+    GSS_REQUIRE(ctx, (int64_t)F * T * D < (1LL << 31), GSS_ERR_UNSUPPORTED,
+                "F * T * D = %lld STFT bins: 2^31 or more are not supported (some kernels index "
+                "the tensor with 32 bits)", (long long)((int64_t)F * T * D));
     GSS_TRY(arena_reserve(ctx, mvdr_workspace_bytes(F, T, D)));
     return mvdr_run(ctx, reinterpret_cast<const cplx *>(Y), F, T, D, mx, mn, ban,
                     reinterpret_cast<cplx *>(Xhat), nullptr, /*gev=*/1);
@@ -544,6 +559,9 @@ static int enhance_observation_impl(gss_ctx *ctx, const gss_params *p, const voi
                 "activity covers %lld frames but the observation has %lld",
                 (long long)T_act, (long long)T);
 
+    GSS_REQUIRE(ctx, (int64_t)F * T * D < (1LL << 31), GSS_ERR_UNSUPPORTED,
+                "F * T * D = %lld STFT bins: 2^31 or more are not supported (some kernels index "
+                "the tensor with 32 bits)", (long long)((int64_t)F * T * D));
     GSS_TRY(arena_reserve(ctx, pipeline_workspace(p, F, T, T_act, D, K)));
     cplx *Y = arena_alloc_t<cplx>(ctx, (size_t)F * T * D);
     cplx *X = p->wpe ? arena_alloc_t<cplx>(ctx, (size_t)F * T * D) : Y;

@@ -806,6 +806,14 @@ def test_unsupported_sizes_fail_loudly(gpu_ctx):
         ops.stft(np.zeros(40000), size=8192, shift=2048)
     with pytest.raises(ValueError):
         ops.enhance_observation(np.zeros((2, 4000)), np.ones((2, 100), bool), 0, 0, 0)
+    # 2^31 STFT bins or more (24 channels: 48 minutes in one piece; a 15-minute utterance runs,
+    # tools/long_utterance_check.py): refused before anything is touched
+    from ctypes import c_void_p
+    buf = gpu_ctx.empty(64)
+    T = (1 << 31) // (513 * 24) + 1
+    with pytest.raises(NotImplementedError, match='STFT bins'):
+        gpu_ctx._check(gpu_ctx.lib.gss_wpe(gpu_ctx.handle, c_void_p(buf.ptr), 513, T, 24, 10, 2, 3,
+                                           0, c_void_p(buf.ptr + 32)), 'gss_wpe')
 
 
 def test_utterance_pipeline_is_bit_identical_to_one_at_a_time(gpu_ctx):
