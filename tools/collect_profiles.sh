@@ -4,7 +4,7 @@
 # --kernel-trace only).  Output under gpurun_out/; summaries: tools/pmc_traffic.py,
 # tools/pmc_mfma.py, tools/pmc_summary.py.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r03b}
+TAG=${1:-r03c}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 # the full default line (session mode, configs table, sharded config 3, CPU baseline) ...
