@@ -512,8 +512,12 @@ def get_gev_vector(target_psd_matrix, noise_psd_matrix):
 
 
 def beamform_gev_from_masks(Y, X_mask, N_mask, ban=True):
-    """beamforming_wrapper.py:192-208 for Y (D,T,F) and 2-D masks (T,F)."""
+    """beamforming_wrapper.py:192-208 for Y (D,T,F) and 2-D masks (T,F).  (The wrapper builds
+    the same _Beamformer object as the MVDR entry point: its ``assert D < 30``,
+    beamforming_wrapper.py:44, applies here too.)"""
     Yf = Y.transpose(2, 0, 1)
+    F, D, T = Yf.shape
+    assert D < 30, (D, Yf.shape)
     cov_x = get_power_spectral_density_matrix(Yf, X_mask.T)
     cov_n = get_power_spectral_density_matrix(Yf, N_mask.T)
     w = get_gev_vector(cov_x, cov_n)
