@@ -1,0 +1,84 @@
+"""Random guided-EM inputs against the oracle and the brute-force EM of
+tests/test_oracle_independent.py: 1 - 32 channels, 1 - 19 classes, 8 - 300 frames, classes that
+are active for a handful of frames or never, 1 - 5 iterations, 0 - 2 post iterations.  Where
+oracle and brute force agree to d, the GPU has to agree with the oracle to 30 d + 1e-8: any two
+float64 implementations drift apart on classes with fewer frames than channels, and oracle and
+brute force share LAPACK's eigh, so d underestimates that drift (worst ratio seen over 1300
+cases: 16, at absolute differences below 1e-6; the convergence bug this sweep family found sat
+at 7000).
+    python tools/fuzz_em.py [SEED] [CASES]"""
+import sys
+import warnings
+from pathlib import Path
+
+import numpy as np
+
+R = Path(__file__).resolve().parents[1]
+for p in (str(R), str(R / 'oracle'), str(R / 'tests')):
+    sys.path.insert(0, p)
+
+
+def main():
+    import gss_oracle as oracle
+    from pb_chime5_amd import ops
+    from test_oracle_independent import brute_force_guided_em
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    rng = np.random.default_rng(seed)
+    warnings.simplefilter('ignore')
+    bad = 0
+    worst_ratio = 0.0
+    for case in range(cases):
+        D = int(rng.integers(1, 33)); K = int(rng.integers(1, 20))
+        T = int(rng.integers(8, 300)); F = int(rng.integers(1, 4))
+        it = int(rng.integers(1, 6)); post = int(rng.integers(0, 3))
+        act = np.zeros((K, T), bool)
+        act[-1] = True                                           # garbage class
+        for k in range(K - 1):
+            mode = int(rng.integers(0, 5))
+            if mode == 0:
+                continue                                         # never active
+            a = int(rng.integers(0, T)); b = a + int(rng.integers(1, 6 if mode == 1 else T))
+            act[k, a:b] = True
+        if rng.integers(0, 6) == 0:
+            act[-1] = rng.uniform(size=T) < 0.5                  # frames nobody claims
+        steer = rng.standard_normal((F, K, D)) + 1j * rng.standard_normal((F, K, D))
+        src = (rng.standard_normal((F, K, T)) + 1j * rng.standard_normal((F, K, T))) * act[None]
+        obs = np.einsum('fkd,fkt->dtf', steer, src)
+        obs = obs + 10.0 ** rng.uniform(-2, 0) * (rng.standard_normal(obs.shape) + 1j * rng.standard_normal(obs.shape))
+        tag = dict(case=case, D=D, K=K, T=T, F=F, it=it, post=post, active=act.sum(axis=1).tolist())
+        res = {}
+        for side, fn in (('oracle', lambda: oracle.gss_block_batched(obs, act, iterations=it, iterations_post=post)),
+                         ('gpu', lambda: ops.cacgmm_posteriors(obs, act, it, post))):
+            try:
+                res[side] = fn()
+            except (AssertionError, NotImplementedError, np.linalg.LinAlgError) as e:
+                res[side] = type(e).__name__ + ': ' + str(e)[:80]
+        o, g = res['oracle'], res['gpu']
+        if isinstance(o, str) or isinstance(g, str):
+            if isinstance(o, str) != isinstance(g, str):
+                print('only one side raises:', 'oracle', o if isinstance(o, str) else '-', '| gpu',
+                      g if isinstance(g, str) else '-', tag)
+                bad += 1
+            continue
+        if np.isnan(o).any() or np.isnan(g).any():
+            if not np.array_equal(np.isnan(o), np.isnan(g)):
+                print('NaN pattern differs', int(np.isnan(o).sum()), int(np.isnan(g).sum()), tag)
+                bad += 1
+            continue
+        d_go = np.max(np.abs(g - o))
+        if d_go < 1e-8:
+            continue
+        f = int(np.argmax(np.max(np.abs(g - o), axis=(0, 1))))
+        b = brute_force_guided_em(np.ascontiguousarray(obs[..., f].T), act, it, post)
+        d_ob = np.max(np.abs(o[..., f] - b))
+        d_gof = np.max(np.abs(g[..., f] - o[..., f]))
+        worst_ratio = max(worst_ratio, d_gof / max(d_ob, 1e-9))
+        if not d_gof <= 30 * d_ob + 1e-8:
+            print('EM', d_gof, 'oracle-brute', d_ob, 'frequency', f, tag)
+            bad += 1
+    print('em fuzz: seed', seed, 'cases', cases, 'failures', bad, 'worst GPU-oracle / oracle-brute', worst_ratio)
+
+
+if __name__ == '__main__':
+    main()
