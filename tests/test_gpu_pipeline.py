@@ -954,7 +954,7 @@ def _fuzz_case(gpu_ctx, ref_mismatches, case, D, K, N, ctx_s, kw, wide=False):
         return 'ill-conditioned WPE'    # both results rounding-decided: nothing downstream compares
     # the masks: equal to 1e-6, or -- classes left with fewer effective frames than channels
     # have a continuum of eigenvalues that the model's 1e-10 floor cuts through, and any two
-    # float64 implementations then disagree -- the GPU is no further from the oracle than 10 x
+    # float64 implementations then disagree -- the GPU is no further from the oracle than 30 x
     # the brute-force EM of tests/test_oracle_independent.py on the frequency that differs most
     if wide and np.abs(wdet['X_hat']).max() < 1e-30 * np.abs(wdet['Obs']).max():
         # a target whose posterior never rises above e.g. 1e-170 (17 frames, 26 channels): the
@@ -978,7 +978,7 @@ def _fuzz_case(gpu_ctx, ref_mismatches, case, D, K, N, ctx_s, kw, wide=False):
         o = oracle.gss_block_batched(Of, act, iterations=it, iterations_post=post)[..., 0]
         b = brute_force_guided_em(np.ascontiguousarray(Of[..., 0].T), act, it, post)
         d_go, d_ob = np.max(np.abs(g - o)), np.max(np.abs(o - b))
-        assert d_go <= 10 * d_ob + 1e-8, (tag, "EM of frequency", f, d_go, d_ob)
+        assert d_go <= 30 * d_ob + 1e-8, (tag, "EM of frequency", f, d_go, d_ob)
         return 'sensitive EM'
     if bf == 'mvdrSouden_ban':
         # bins with a nearly singular Phi_N are decided by rounding in the reference too
