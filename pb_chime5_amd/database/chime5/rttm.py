@@ -161,14 +161,21 @@ class RTTMDatabase:
             sessions.extend(self._alias.get(s, (s,)))
         out = []
         for session_id in sessions:
+            # One example per RTTM line, in file order per speaker: the reference walks
+            # ``speaker.intervals`` (rttm.py:466), the segments as they were assigned -- NOT
+            # merged or sorted, so two touching segments of a speaker stay two utterances --
+            # into a dict keyed by the example id (a repeated line is one example).
+            examples = {}
             for speaker_id, speaker in self._rttm[session_id].items():
-                for start, end in speaker.normalized_intervals:
-                    out.append({
-                        'example_id': self.example_id(session_id, speaker_id, start, end),
+                for start, end in speaker.intervals:
+                    example_id = self.example_id(session_id, speaker_id, start, end)
+                    examples[example_id] = {
+                        'example_id': example_id,
                         'start': start, 'end': end, 'num_samples': end - start,
                         'session_id': session_id, 'speaker_id': speaker_id,
                         'audio_path': self._audio_paths[session_id], 'dataset': session_id,
-                    })
+                    }
+            out.extend(examples.values())
         return out
 
     def get_dataset_for_session(self, session, *, audio_read=False, adjust_times=False,

@@ -169,6 +169,31 @@ def test_rttm_with_nine_speakers_runs_like_the_reference(gpu_ctx, tmp_path):
 GOLDEN = __import__('pathlib').Path(__file__).parent / 'golden'
 
 
+def test_one_example_per_rttm_line_in_file_order(tmp_path):
+    """The reference walks the segments of a speaker as the RTTM lists them (rttm.py:466,
+    ``speaker.intervals``: not merged, not sorted): two touching segments are two utterances, an
+    earlier segment further down the file comes later, a repeated line is one example.  (Found by
+    tests/golden/fuzz_rttm_vs_reference.py, which runs random RTTM files through the reference's
+    own front door and this one: 120 files, identical examples and activity.)"""
+    from pb_chime5_amd.core_chime6_rttm import get_enhancer
+    root, rttm_file, _ = _make_chime6_dir(tmp_path)
+    rttm_file.write_text(
+        'SPEAKER S02_U06.ENH 1 0.50 0.50 <NA> <NA> P05 <NA>\n'
+        'SPEAKER S02_U06.ENH 1 1.00 0.25 <NA> <NA> P05 <NA>\n'
+        'SPEAKER S02_U06.ENH 1 0.70 0.10 <NA> <NA> P06 <NA>\n'
+        'SPEAKER S02_U06.ENH 1 0.20 0.10 <NA> <NA> P05 <NA>\n'
+        'SPEAKER S02_U06.ENH 1 1.00 0.25 <NA> <NA> P05 <NA>\n')
+    enh = get_enhancer(database_rttm=str(rttm_file), activity_rttm=str(rttm_file),
+                       chime6_dir=str(root), multiarray='first_array_mics', context_samples=0,
+                       wpe=False, bss_iterations=1)
+    got = [(ex['speaker_id'], ex['start'], ex['end']) for ex in enh.get_dataset('dev')]
+    assert got == [('P05', 8000, 16000), ('P05', 16000, 20000), ('P05', 3200, 4800),
+                   ('P06', 11200, 12800)]
+    # the activity, on the other hand, is the merged one
+    assert [tuple(map(int, iv)) for iv in enh.activity['S02']['P05'].normalized_intervals] == \
+        [(3200, 4800), (8000, 20000)]
+
+
 def _reference_setup(tmp_path):
     """The directory and RTTM that tests/golden/make_golden_rttm.py fed to the reference's
     own rttm.py / core_chime6_rttm.py (the RTTM restricted to the session that has audio:
