@@ -65,9 +65,9 @@ typedef enum {
 
 /* ABI revision of this header.  Bumped whenever an entry point changes its argument list
  * or a struct its layout (round 2 added `psd_context` to gss_wpe and `wpe_psd_context` to
- * gss_params: revision 2; round 3 added entry points only: revision 3).  A binder compares
+ * gss_params: revision 2; rounds 3 and 4 added entry points only: revisions 3, 4).  A binder compares
  * gss_abi_version() with the GSS_ABI_VERSION it was written against before any other call. */
-#define GSS_ABI_VERSION 3
+#define GSS_ABI_VERSION 4
 int gss_abi_version(void);
 
 /* ---- context ----------------------------------------------------------- */
@@ -138,6 +138,14 @@ int gss_activity_time_to_frequency(gss_ctx *ctx, const uint8_t *act_dev, int K,
  * default.  Y (F,T,D) -> X (F,T,D); X must not alias Y unless iterations == 0. */
 int gss_wpe(gss_ctx *ctx, const gss_cplx *Y_dev, int F, int64_t T, int D,
             int taps, int delay, int iterations, int psd_context, gss_cplx *X_dev);
+
+/* The weights of one WPE iteration on their own: nara_wpe.wpe.get_power_inverse(Y,
+ * psd_context) as wpe_v6 calls it (mean over channels of |Y|^2, optionally averaged over
+ * the existing frames of [t - psd_context, t + psd_context], floored at 1e-10 * its maximum
+ * over time, inverted).  Y (F,T,D) -> inverse_power (F,T).  A stage entry point for
+ * checking the smoothing on its own; gss_wpe computes the same thing inside. */
+int gss_wpe_inverse_power(gss_ctx *ctx, const gss_cplx *Y_dev, int F, int64_t T, int D,
+                          int psd_context, double *inverse_power_dev);
 
 /* A4-A6  GSS.__call__ (core.py:154-214): initialisation from the frame activity,
  * CACGMMTrainer.fit(iterations, source_activity_mask) and the post step

@@ -18,7 +18,7 @@ GSS_ERR_INVALID = -1
 GSS_ERR_HIP = -2
 GSS_ERR_NOMEM = -3
 GSS_ERR_UNSUPPORTED = -4
-GSS_ABI_VERSION = 3       # include/gss_hip.h revision these prototypes are written against
+GSS_ABI_VERSION = 4       # include/gss_hip.h revision these prototypes are written against
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -68,6 +68,8 @@ SIGNATURES = {
         c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     'gss_wpe': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int,
                         c_int, c_int, c_void_p]),
+    'gss_wpe_inverse_power': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int,
+                                      c_void_p]),
     'gss_cacgmm': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p,
                            c_int, c_int, c_int, c_void_p]),
     'gss_masks_from_posteriors': (

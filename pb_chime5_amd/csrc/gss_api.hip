@@ -391,6 +391,21 @@ extern "C" int gss_wpe(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T, int D,
                    psd_context, reinterpret_cast<cplx *>(X));
 }
 
+extern "C" int gss_wpe_inverse_power(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T, int D,
+                                     int psd_context, double *inverse_power) {
+    GSS_ENTER(ctx);
+    GSS_REQUIRE(ctx, Y && inverse_power && F >= 1 && T >= 1 && psd_context >= 0, GSS_ERR_INVALID,
+                "gss_wpe_inverse_power: bad arguments");
+    GSS_REQUIRE(ctx, D >= 1 && D <= GSS_MAX_CHANNELS, GSS_ERR_UNSUPPORTED,
+                "gss_wpe_inverse_power: D=%d outside [1, %d]", D, GSS_MAX_CHANNELS);
+    GSS_REQUIRE(ctx, (int64_t)F * T * D < (1LL << 31), GSS_ERR_UNSUPPORTED,
+                "F * T * D = %lld STFT bins: 2^31 or more are not supported",
+                (long long)((int64_t)F * T * D));
+    GSS_TRY(arena_reserve(ctx, sizeof(double) * (size_t)F * T + 8192));
+    return wpe_inverse_power_run(ctx, reinterpret_cast<const cplx *>(Y), F, T, D, psd_context,
+                                 inverse_power);
+}
+
 static int check_cacgmm_args(gss_ctx *ctx, int D, int K, int iterations, int post) {
     GSS_REQUIRE(ctx, D >= 2 && D <= GSS_MAX_CHANNELS, GSS_ERR_UNSUPPORTED,
                 "cacgmm: D=%d outside [2, %d]", D, GSS_MAX_CHANNELS);
@@ -576,6 +591,8 @@ static int enhance_observation_impl(gss_ctx *ctx, const gss_params *p, const voi
     const size_t mark = ctx->arena_off;
 
     GSS_TRY(stft_run(ctx, obs, obs_type, D, N, fading, Y));
+    if (!p->wpe)    // no solve in this call: clear the count an earlier utterance left behind
+        GSS_HIP_CHECK(ctx, hipMemsetAsync(ctx->status_dev + 2, 0, sizeof(int32_t), ctx->stream));
     if (p->wpe) {
         GSS_TRY(wpe_run(ctx, Y, F, T, D, p->wpe_taps, p->wpe_delay, p->wpe_iterations,
                         p->wpe_psd_context, X));

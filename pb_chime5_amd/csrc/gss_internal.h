@@ -212,6 +212,8 @@ struct ProfScope {
 // ---------------------------------------------------------------- stage launchers
 // (device pointers, workspace from the arena, asynchronous on ctx->stream)
 size_t wpe_workspace_bytes(int F, int64_t T, int D, int taps, int delay);
+int wpe_inverse_power_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int psd_context,
+                          double *w);
 int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int delay,
             int iterations, int psd_context, cplx *X);
 

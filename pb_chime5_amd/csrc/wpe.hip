@@ -82,23 +82,36 @@ __global__ __launch_bounds__(POW_FRAMES) void wpe_power_kernel(const cplx *__res
             }
         } else {
             // long windows: every thread takes a run of consecutive frames, sums the first
-            // window and slides it (O(T / 256 + p) per thread instead of O(T p / 256))
+            // window and slides it (O(T / 256 + p) per thread instead of O(T p / 256)).  The
+            // running sum is kept as an unevaluated pair (sum, carry) updated with error-free
+            // additions: a plain `sum += in; sum -= out` keeps eps * (the loudest frame that
+            // ever was in the window) after that frame has left -- a relative error of 1e-6
+            // in the power of frames 100 dB below it, and a result that depends on where the
+            // 256 runs start -- while np.correlate sums every window afresh.  With the pair
+            // the slid sum equals the fresh one to ~eps^2 of the loud frame.
             const int64_t run = (T + POW_FRAMES - 1) / POW_FRAMES;
             const int64_t t_beg = (int64_t)tid * run, t_end = t_beg + run < T ? t_beg + run : T;
-            double sum = 0.0;
+            double sum = 0.0, carry = 0.0;
+            auto add = [&](double x) {
+                const double s = sum + x;
+                const double bb = s - sum;
+                const double err = (sum - (s - bb)) + (x - bb);       // two-sum: s + err == sum + x
+                carry += err;
+                sum = s;
+            };
             int64_t lo = 0, hi = -1;
             for (int64_t t = t_beg; t < t_end; ++t) {
                 const int64_t nlo = t - psd_context > 0 ? t - psd_context : 0;
                 const int64_t nhi = t + psd_context < T - 1 ? t + psd_context : T - 1;
                 if (t == t_beg) {
-                    for (int64_t u = nlo; u <= nhi; ++u) sum += wf[u];
+                    for (int64_t u = nlo; u <= nhi; ++u) add(wf[u]);
                 } else {
-                    if (nhi > hi) sum += wf[nhi];
-                    if (nlo > lo) sum -= wf[lo];
+                    if (nhi > hi) add(wf[nhi]);
+                    if (nlo > lo) add(-wf[lo]);
                 }
                 lo = nlo;
                 hi = nhi;
-                const double p = sum / (double)(hi - lo + 1);
+                const double p = (sum + carry) / (double)(hi - lo + 1);
                 wout[t] = p;
                 mx = fmax(mx, p);
             }
@@ -1313,11 +1326,34 @@ size_t wpe_workspace_bytes(int F, int64_t T, int D, int taps, int delay) {
     return b + 4096;
 }
 
+static int wpe_power_launch(gss_ctx *ctx, const cplx *cur, int F, int64_t T, int D,
+                            int psd_context, double *raw, double *w) {
+    const size_t pow_lds = sizeof(double) * POW_FRAMES * (D + 1);
+    if (pow_lds > 64 * 1024)
+        GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(wpe_power_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)pow_lds));
+    hipLaunchKernelGGL(wpe_power_kernel, dim3(F), dim3(POW_FRAMES), pow_lds, ctx->stream,
+                       cur, T, D, psd_context, raw, w);
+    GSS_LAUNCH_CHECK(ctx, "wpe_power_kernel");
+    return GSS_OK;
+}
+
+// gss_wpe_inverse_power: the weights of one WPE iteration on their own
+int wpe_inverse_power_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int psd_context,
+                          double *w) {
+    double *raw = psd_context > 0 ? arena_alloc_t<double>(ctx, (size_t)F * T) : nullptr;
+    GSS_REQUIRE(ctx, raw || psd_context == 0, GSS_ERR_NOMEM, "wpe power workspace");
+    return wpe_power_launch(ctx, Y, F, T, D, psd_context, raw, w);
+}
+
 int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int delay,
             int iterations, int psd_context, cplx *X) {
     const int n = taps * D;
     const int c = delay + taps - 1;
     if (iterations == 0) {
+        // nothing is solved: gss_last_wpe_zero_pivots() must not report an earlier call's count
+        GSS_HIP_CHECK(ctx, hipMemsetAsync(ctx->status_dev + 2, 0, sizeof(int32_t), ctx->stream));
         if (X != Y)
             GSS_HIP_CHECK(ctx, hipMemcpyAsync(X, Y, sizeof(cplx) * (size_t)F * T * D,
                                               hipMemcpyDeviceToDevice, ctx->stream));
@@ -1515,14 +1551,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         const cplx *cur = it == 0 ? Y : X;
         {
             GSS_PROF(ctx, "wpe_power");
-            const size_t pow_lds = sizeof(double) * POW_FRAMES * (D + 1);
-            if (pow_lds > 64 * 1024)
-                GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(wpe_power_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       (int)pow_lds));
-            hipLaunchKernelGGL(wpe_power_kernel, dim3(F), dim3(POW_FRAMES), pow_lds, ctx->stream,
-                               cur, T, D, psd_context, raw, w);
-            GSS_LAUNCH_CHECK(ctx, "wpe_power_kernel");
+            GSS_TRY(wpe_power_launch(ctx, cur, F, T, D, psd_context, raw, w));
         }
         {
             GSS_PROF(ctx, "wpe_corr");

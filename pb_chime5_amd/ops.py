@@ -180,6 +180,21 @@ def wpe_dtf(Obs, taps=10, delay=2, iterations=3, psd_context=0, *, ctx=None):
     return _ftd_to_host_dtf(ctx, X_d, D, T, F)
 
 
+def get_power_inverse(signal, psd_context=0, *, ctx=None):
+    """nara_wpe.wpe.get_power_inverse: signal (F, D, T) -> (F, T), the weights of one WPE
+    iteration (mean channel power, smoothed over [t - psd_context, t + psd_context], floored
+    at 1e-10 of its maximum over time, inverted)."""
+    psd_context = check_psd_context(psd_context)
+    ctx = ctx or default_context()
+    signal = np.asarray(signal, dtype=np.complex128)
+    Y_d, (D, T, F) = _obs_to_device_ftd(ctx, signal.transpose(1, 2, 0))
+    w_d = ctx.empty(8 * F * T)
+    ctx._check(ctx.lib.gss_wpe_inverse_power(ctx.handle, c_void_p(Y_d.ptr), F, T, D,
+                                             int(psd_context), c_void_p(w_d.ptr)),
+               'gss_wpe_inverse_power')
+    return ctx.to_host(w_d, (F, T), np.float64)
+
+
 def wpe_v8(Y, taps=10, delay=3, iterations=3, psd_context=0, *, ctx=None):
     """nara_wpe.wpe.wpe_v8 signature: Y (..., D, T) with the frequency (independent)
     axes leading; returns the same shape."""
@@ -385,6 +400,7 @@ class UtterancePipeline:
         self._bufs = [dict() for _ in self.slots]
         self._pending = deque()
         self._next = 0
+        self.dropped = []       # tags close() drained without handing out their result
 
     def __len__(self):
         return len(self._pending)
@@ -437,10 +453,15 @@ class UtterancePipeline:
     def close(self):
         """Drain what is still in flight WITHOUT the status check (close() runs in `finally`
         blocks: a second exception here would mask the first one and leak the extra
-        contexts), then release buffers and contexts."""
+        contexts), then release buffers and contexts.  Consequence for a caller that enqueues
+        and closes without pop(): the AssertionError / LinAlgError the reference would raise
+        for those utterances (non-finite SNR, indefinite noise PSD) is NOT raised -- their
+        results are discarded unseen.  pop() every utterance whose outcome matters
+        (`Enhancer._enhance_and_write` does); `self.dropped` lists the tags close() drained."""
         try:
             while self._pending:
-                _, slot, _ = self._pending.popleft()
+                tag, slot, _ = self._pending.popleft()
+                self.dropped.append(tag)
                 try:
                     self.slots[slot].synchronize()
                 except Exception:

@@ -25,7 +25,24 @@ def _normalize(intervals):
     return tuple(out)
 
 
+def ArrayIntervall_from_str(string, shape):
+    """``'1:4, 5:20'`` -> intervals (utils/intervall_array.py:12-42).  A module-level name on
+    purpose: the reference's ``__reduce__`` hands pickle ``staticmethod(ArrayIntervall_from_str)``
+    (:104,164), so its activity pickles name ``...intervall_array.ArrayIntervall_from_str``."""
+    ai = ArrayIntervall(shape)
+    pairs = []
+    for item in string.split(','):
+        item = item.strip()
+        if item:
+            s, e = item.split(':')
+            pairs.append((int(s), int(e)))
+    ai._intervals = _normalize(pairs)
+    return ai
+
+
 class ArrayIntervall:
+    from_str = staticmethod(ArrayIntervall_from_str)
+
     def __init__(self, shape):
         if isinstance(shape, (int, np.integer)):
             shape = [int(shape)]
@@ -36,19 +53,6 @@ class ArrayIntervall:
         self._intervals = ()
 
     # ---- construction --------------------------------------------------
-    @staticmethod
-    def from_str(string, shape):
-        """``'1:4, 5:20'`` -> intervals."""
-        ai = ArrayIntervall(shape)
-        pairs = []
-        for item in string.split(','):
-            item = item.strip()
-            if item:
-                s, e = item.split(':')
-                pairs.append((int(s), int(e)))
-        ai._intervals = _normalize(pairs)
-        return ai
-
     @staticmethod
     def from_array(array):
         array = np.asarray(array)

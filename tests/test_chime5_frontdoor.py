@@ -330,49 +330,36 @@ def test_session_tables_match_reference():
 
 def test_activity_path_loads_pickles_written_by_the_reference(tmp_path):
     """Activity(type='path') (core.py:135-139) unpickles per-session dicts of the REFERENCE'S
-    ArrayIntervall objects: pickles that name `pb_chime5.utils.intervall_array` must load
-    without that package (missing #5).  The pickle is written here through a
-    stand-in module of that name with the reference's __reduce__ protocol
-    (utils/intervall_array.py:145-165: `from_str, (intervals_as_str, shape[-1])`)."""
+    ArrayIntervall objects without that package.  tests/golden/activity_reference.pkl was
+    written by the reference's own utils/intervall_array.py (make_golden_activity_pickle.py):
+    its __reduce__ names the module-level `ArrayIntervall_from_str`; the JSON next
+    to it holds what the reference's objects answer."""
     import pickle
-    import sys
-    import types
+    import shutil
     from pb_chime5_amd.core import Activity
     from pb_chime5_amd.utils.intervall_array import ArrayIntervall as Ours
 
-    class ArrayIntervall:                      # what the reference pickles
-        def __init__(self, text, n):
-            self.text, self.n = text, n
-
-        @staticmethod
-        def from_str(string, shape):
-            raise AssertionError('the stand-in must not be used for loading')
-
-        def __reduce__(self):
-            return ArrayIntervall.from_str, (self.text, self.n)
-
-    ArrayIntervall.__qualname__ = 'ArrayIntervall'
-    ArrayIntervall.from_str.__qualname__ = 'ArrayIntervall.from_str'
-    ArrayIntervall.from_str.__module__ = 'pb_chime5.utils.intervall_array'
-    names = ['pb_chime5', 'pb_chime5.utils', 'pb_chime5.utils.intervall_array']
-    saved = {n: sys.modules.get(n) for n in names}
-    try:
-        for n in names:
-            sys.modules[n] = types.ModuleType(n)
-        ArrayIntervall.__module__ = names[-1]
-        sys.modules[names[-1]].ArrayIntervall = ArrayIntervall
-        blob = pickle.dumps({'U01': {'P05': ArrayIntervall('10:20, 35:50', 64),
-                                     'Noise': ArrayIntervall('0:64', 64)}}, protocol=4)
-    finally:
-        for n, m in saved.items():
-            if m is None:
-                sys.modules.pop(n, None)
-            else:
-                sys.modules[n] = m
-    assert b'pb_chime5.utils.intervall_array' in blob and b'pb_chime5_amd' not in blob
-    (tmp_path / 'S02.pkl').write_bytes(blob)
+    blob = (GOLDEN / 'activity_reference.pkl').read_bytes()
+    assert b'pb_chime5.utils.intervall_array' in blob and b'ArrayIntervall_from_str' in blob
+    assert b'pb_chime5_amd' not in blob
+    shutil.copy(GOLDEN / 'activity_reference.pkl', tmp_path / 'S02.pkl')
+    want = json.loads((GOLDEN / 'activity_reference.json').read_text())
     act = Activity(type='path', path=str(tmp_path))['S02']
-    assert isinstance(act['U01']['P05'], Ours)
-    assert act['U01']['P05'].normalized_intervals == ((10, 20), (35, 50))
-    assert act['U01']['P05'][8:12].tolist() == [False, False, True, True]
-    assert act['U01']['Noise'][:].all() and act['U01']['Noise'].shape == (64,)
+    assert sorted(act) == sorted(want)
+    for array, speakers in want.items():
+        assert list(act[array]) == list(speakers)          # dict order = class order
+        for speaker, w in speakers.items():
+            got = act[array][speaker]
+            assert isinstance(got, Ours)
+            assert list(got.shape) == w['shape']
+            assert [list(i) for i in got.normalized_intervals] == w['intervals']
+            for sl in w['slices']:
+                dense = got[sl['start']:sl['stop']]
+                assert dense.dtype == bool and dense.shape == (sl['stop'] - sl['start'],)
+                edges = np.diff(np.concatenate([[0], dense.astype(np.int8), [0]]))
+                runs = [list(map(int, r)) for r in zip(np.flatnonzero(edges > 0),
+                                                       np.flatnonzero(edges < 0))]
+                assert runs == sl['runs'], (array, speaker, sl['start'])
+    # and what this package pickles loads again (same protocol both ways)
+    again = pickle.loads(pickle.dumps(act['U01']['P05']))
+    assert again.normalized_intervals == act['U01']['P05'].normalized_intervals

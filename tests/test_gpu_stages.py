@@ -282,6 +282,41 @@ def test_wpe_zero_channel_is_handled_like_lstsq(gpu_ctx):
     want = oracle.wpe_block(Y, 3, 2, 2)
     assert np.all(got[2] == 0)
     assert rel_err(got, want) < 1e-8
+    # ... and the count of zeroed pivots belongs to THAT call: a later call that solves nothing
+    # (iterations = 0; the fused pipeline with wpe=False) reports 0, not this count
+    assert gpu_ctx.last_wpe_zero_pivots() > 0
+    assert np.array_equal(ops.wpe_dtf(Y, 3, 2, 0, ctx=gpu_ctx), Y)
+    assert gpu_ctx.last_wpe_zero_pivots() == 0
+    ops.wpe_dtf(Y, 3, 2, 1, ctx=gpu_ctx)
+    assert gpu_ctx.last_wpe_zero_pivots() > 0
+    from pb_chime5_amd import synthetic
+    u = synthetic.tiny(num_channels=4, num_samples=8000, num_speakers=2, context=1024)
+    ops.enhance_observation(u.obs, u.activity_array, u.target_index, 1024, 1024, ctx=gpu_ctx,
+                            wpe=False, bss_iterations=2)
+    assert gpu_ctx.last_wpe_zero_pivots() == 0
+
+
+@pytest.mark.parametrize('psd_context', [0, 3, 16, 17, 40, 300, np.inf])
+def test_wpe_inverse_power_with_100_db_of_dynamic_range(gpu_ctx, psd_context):
+    """gss_wpe_inverse_power = nara_wpe get_power_inverse, checked frame by frame on a signal
+    with bursts 100 dB above a quiet floor.  For psd_context > 16 the kernel slides its window
+    sum along runs of T / 256 frames; a plain running sum keeps eps * (burst power) after the
+    burst has left the window -- 1e-6 of the quiet power -- where np.correlate sums every
+    window afresh: the pair-compensated sum must not."""
+    from pb_chime5_amd import ops
+    rng = np.random.default_rng(99)
+    F, D, T = 3, 4, 5300                     # runs of 21 frames per thread
+    Y = crandn(rng, F, D, T)
+    for t0 in (0, 700, 701, 2048, 2100, 4000, T - 1):
+        Y[:, :, t0:t0 + int(rng.integers(1, 4))] *= 1e5
+    got = ops.get_power_inverse(Y, psd_context, ctx=gpu_ctx)
+    want = np.array([oracle.get_power_inverse(Y[f], psd_context) for f in range(F)])
+    assert got.shape == want.shape == (F, T)
+    err = np.max(np.abs(got - want) / want)
+    print(f'psd_context {psd_context}: inverse power max rel err {err:.2e}, '
+          f'dynamic range {want.max() / want.min():.1e}')
+    assert want.max() / want.min() > 1e7 or np.isinf(psd_context)
+    assert err < 1e-12
 
 
 # ---------------------------------------------------------------- CACGMM
