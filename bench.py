@@ -512,7 +512,14 @@ def parse_args():
     ap.add_argument('--steps', type=int, default=None,
                     help='config 2: timed steps per rank (default 20); config 3: items (default 512)')
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--config', type=int, default=2, choices=(2, 3))
+    ap.add_argument('--config', default='2', choices=('2', '3', '4s'),
+                    help="2: the headline (+ everything else unless --only-headline); 3: BASELINE "
+                         "configs[2] alone; 4s: the file-backed stand-in for configs[3] alone")
+    ap.add_argument('--session-seconds', type=float, default=660.0,
+                    help='config 4s: length of the synthetic dev-shaped session')
+    ap.add_argument('--session-utterances', type=int, default=220)
+    ap.add_argument('--loaders', type=int, default=3, help='config 4s: loader threads per rank')
+    ap.add_argument('--no-config4s', action='store_true')
     ap.add_argument('--items', type=int, default=512,
                     help='config-3 items in the config3_sharded block of a --config 2 run')
     ap.add_argument('--pool', type=int, default=2, help='config-3 base recordings')
@@ -662,7 +669,125 @@ def main():
                               gpu_wait_s=v[6]) for r, v in enumerate(per_rank)],
         }
 
-    if args.config == 3:
+    # ------------------------------------------------------------------ config 4 stand-in
+    def config4s_session():
+        """BASELINE configs[3] stand-in (the CHiME-5 audio is not available): a synthetic
+        session in the CHiME-5 layout at dev shape -- 24 per-channel PCM16 WAV files,
+        `--session-utterances` utterances with 2 x 15 s of context -- on tmpfs / local disk,
+        through Enhancer.enhance_session exactly as `python -m pb_chime5_amd.scripts.run with
+        session_id=S02 multiarray=True` runs it: JSON database, annotation activity, WAV slice
+        reads, PCM16 upload, enhancement, context trim, WAV writes; wall clock around all of it,
+        all ranks pulling examples from the shared longest-first queue."""
+        import shutil
+        import tempfile
+        from pb_chime5_amd.core import get_enhancer
+        from pb_chime5_amd.synthetic_corpus import write_dev_shaped_session
+        base = os.environ.get('GSS_BENCH_SCRATCH')
+        if base is None:
+            shm = Path('/dev/shm')
+            ok = shm.is_dir() and os.access(shm, os.W_OK) and shutil.disk_usage(shm).free > 4 << 30
+            base = str(shm) if ok else tempfile.gettempdir()
+        tag = os.environ.get('MASTER_PORT', '0') if world > 1 else f'p{os.getpid()}'
+        root = Path(base) / f'gss_bench_c4s_{tag}'
+        t_gen = time.perf_counter()
+        if rank == 0:
+            shutil.rmtree(root, ignore_errors=True)
+            write_dev_shaped_session(root / 'corpus', seconds=args.session_seconds,
+                                     num_utterances=args.session_utterances)
+        barrier()
+        t_gen = time.perf_counter() - t_gen
+        json_path = root / 'corpus' / 'chime5.json'
+        kw = dict(database_path=str(json_path), multiarray=True, context_samples=240000,
+                  device_id=device_index)
+
+        def obs_samples(ex):
+            return max(ex['num_samples']['observation'].values())
+        try:
+            # warm-up on a second Enhancer (workspaces sized, code objects loaded, page cache
+            # of the WAV files touched); the timed Enhancer below starts cold on the host side:
+            # JSON parse, activity tracks from the annotations, file opens are in the wall clock
+            warm = get_enhancer(**kw)
+            warm.inflight, warm.loaders = args.inflight, args.loaders
+            examples = sorted(warm.get_iterator('S02'), key=obs_samples)
+            (root / f'warm{rank}' / 'dev').mkdir(parents=True)
+            warm._enhance_and_write(examples[-(args.inflight + 1):], root / f'warm{rank}')
+            del warm
+            enh = get_enhancer(**kw)
+            enh.inflight, enh.loaders = args.inflight, args.loaders
+            barrier()
+            t0 = time.perf_counter()
+            enh.enhance_session('S02', root / 'out', audio_dir_exist_ok=True)
+            local = time.perf_counter() - t0
+            barrier()
+            wall = max_over_ranks(time.perf_counter() - t0)
+            clock = enh.session_clock
+            keys = ('wall_s', 'examples', 'host_wait_s', 'enqueue_s', 'gpu_wait_s', 'write_wait_s',
+                    'loader_busy_s', 'writer_busy_s')
+            per_rank = gather_over_ranks([local] + [clock[k] for k in keys])
+            written = sorted((root / 'out' / 'dev').glob('*.wav')) if rank == 0 else []
+            if rank == 0:
+                assert len(written) == len(examples), (len(written), len(examples))
+                out_bytes = sum(p.stat().st_size for p in written)
+                in_bytes = sum(p.stat().st_size for p in (root / 'corpus' / 'audio' / 'dev').glob('*.wav'))
+            secs = sum(obs_samples(ex) for ex in examples) / SR
+            core = sum(ex['num_samples_orig']['observation'][ex['reference_array']]
+                       for ex in examples) / SR
+        finally:
+            barrier()
+            if rank == 0:
+                shutil.rmtree(root, ignore_errors=True)
+        if rank != 0:
+            return None
+        return {
+            'workload': (f'BASELINE.json configs[3] stand-in: synthetic CHiME-5-layout session S02, '
+                         f'{args.session_seconds:.0f} s x 24 per-channel PCM16 WAV files '
+                         f'({in_bytes / 1e6:.0f} MB) under {base}, {len(examples)} utterances '
+                         '(dev-shaped lengths, 2 x 15 s context, all 6 arrays = 24 ch, K = 5), '
+                         'get_enhancer() defaults: WPE taps=10, 20 EM iterations, MVDR+BAN'),
+            'driver': 'Enhancer.enhance_session(\'S02\', out) as scripts/run.py calls it',
+            'includes': ('JSON database + annotation activity, WAV slice reads into page-locked '
+                         'int16 blocks, H2D, enhancement, D2H of the trimmed utterance, peak '
+                         'normalisation + PCM16 WAV writes'),
+            'sharding': ('dynamic: shared counter in the launcher\'s TCP store, longest first '
+                         '(parallel.split_managed)') if world > 1 else 'single rank',
+            'utterances': len(examples), 'utterances_in_flight_per_gpu': args.inflight,
+            'loader_threads_per_rank': args.loaders,
+            'utterance_seconds': secs, 'core_seconds_written': core,
+            'wav_bytes_written': out_bytes, 'wall_s': wall,
+            'value': secs / wall, 'unit': 'utterance-seconds/s',
+            'ms_per_utterance': 1e3 * wall / len(examples) * world,
+            'corpus_generation_s': t_gen,
+            # one row per rank.  gpu_wait_s: blocked in pop() for the oldest utterance (the GPU is
+            # the bottleneck when this dominates); host_wait_s: blocked on the loader threads;
+            # loader_busy_s / writer_busy_s: summed busy time of those threads
+            'per_rank': [dict(rank=r, busy_s=v[0], **{k: (int(x) if k == 'examples' else x)
+                                                      for k, x in zip(keys, v[1:])})
+                         for r, v in enumerate(per_rank)],
+            'gpu_wait_share_of_wall': min(v[1 + keys.index('gpu_wait_s')] / wall for v in per_rank),
+        }
+
+    if args.config == '4s':
+        block = config4s_session()
+        if rank == 0:
+            line = {
+                'metric': 'utterance-seconds enhanced/sec (24ch, 20 EM iters), file-backed session',
+                'value': block['value'], 'unit': 'utterance-seconds/s', 'n_gpus': args.gpus,
+                'steps': block['utterances'], 'warmup': args.inflight + 1,
+                'ms_per_step': 1e3 * block['wall_s'] / block['utterances'],
+                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+                'dtype': 'f64', 'data': 'synthetic',
+                'config': {'workload': block['workload'], 'sharding': block['sharding'],
+                           'parallelism': f'utterance-sharded x{args.gpus}'
+                                          + (' (ranks share GPUs)' if shared_devices else '')},
+                'config4_standin': block,
+            }
+            emit(line)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    if args.config == '3':
         items = args.steps or 512
         block = config3_session(items)
         if rank == 0:
@@ -798,13 +923,15 @@ def main():
         timed('5', u5, ops.make_params(wpe=True, wpe_taps=10, wpe_delay=2, wpe_iterations=3,
                                        bss_iterations=40, bss_iterations_post=1, bf='gev_ban'), 3,
               'configs[4]: 120 s segment, 12 ch (outer_array_mics), WPE, 40 EM iterations, GEV + BAN')
-        configs['4'] = {'status': 'not run: corpus unavailable',
+        configs['4'] = {'status': 'corpus unavailable; file-backed stand-in at dev shape: see '
+                                  '`config4_standin` (python bench.py --config 4s)',
                         'workload': 'configs[3]: CHiME-5 dev session S02 (needs the CHiME-5 audio and '
                                     'cache/chime5.json; `python -m pb_chime5_amd.scripts.run with '
                                     'session_id=S02 multiarray=True` is the harness hook)'}
 
     # ---- BASELINE configs[2] through the shared queue (all ranks)
     sharded = config3_session(args.items) if extras else None
+    standin = config4s_session() if extras and not args.no_config4s else None
 
     if rank == 0:
         size = dict(F=F, T=resident.T, D=resident.D, K=resident.K, taps=WORKLOAD['wpe_taps'],
@@ -861,6 +988,7 @@ def main():
             'em_loop': em_loop,
             'configs': configs,
             'config3_sharded': sharded,
+            'config4_standin': standin,
         }
         if args.gpus == 1 and extras and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(utt, args.cpu_bins, args.cpu_workers)

@@ -65,7 +65,7 @@ typedef enum {
 
 /* ABI revision of this header.  Bumped whenever an entry point changes its argument list
  * or a struct its layout (round 2 added `psd_context` to gss_wpe and `wpe_psd_context` to
- * gss_params: revision 2; rounds 3 and 4 added entry points only: revisions 3, 4).  A binder compares
+ * gss_params: revision 2; rounds 3 and 4 added entry points only: revisions 3, 4.  A binder compares
  * gss_abi_version() with the GSS_ABI_VERSION it was written against before any other call. */
 #define GSS_ABI_VERSION 4
 int gss_abi_version(void);
@@ -90,6 +90,18 @@ int gss_dev_free(gss_ctx *ctx, void *dev_ptr);
 int gss_memcpy_h2d(gss_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int gss_memcpy_d2h(gss_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int gss_memset(gss_ctx *ctx, void *dst_dev, int value, size_t bytes);
+/* Page-locked host memory and copies that return at once (ordered on the context's stream;
+ * the host buffer must stay untouched until gss_synchronize() or a later synchronous call
+ * returns).  With pageable memory the *_async forms behave like the plain ones.  The session
+ * driver reads WAV samples straight into such a block (replaces the reference's soundfile
+ * read + float64 conversion + np.array stacking, io/audioread.py:34-226, core.py:427-470).
+ * gss_host_malloc / gss_host_free touch no context state (the context only names the GPU
+ * and receives the error message) and may be called from any thread; gss_host_free does not
+ * synchronise: no copy from / to the block may be in flight. */
+int gss_host_malloc(gss_ctx *ctx, size_t bytes, void **host_ptr);
+int gss_host_free(gss_ctx *ctx, void *host_ptr);
+int gss_memcpy_h2d_async(gss_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int gss_memcpy_d2h_async(gss_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
 /* ---- per-kernel timing (HIP events on the context's stream) -------------- */
 int gss_profile_enable(gss_ctx *ctx, int on);

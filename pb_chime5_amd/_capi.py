@@ -54,6 +54,10 @@ SIGNATURES = {
     'gss_memcpy_h2d': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     'gss_memcpy_d2h': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     'gss_memset': (c_int, [c_void_p, c_void_p, c_int, c_size_t]),
+    'gss_host_malloc': (c_int, [c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
+    'gss_host_free': (c_int, [c_void_p, c_void_p]),
+    'gss_memcpy_h2d_async': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    'gss_memcpy_d2h_async': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     'gss_profile_enable': (c_int, [c_void_p, c_int]),
     'gss_profile_filter': (c_int, [c_void_p, ctypes.c_char_p]),
     'gss_profile_reset': (c_int, [c_void_p]),
@@ -178,6 +182,37 @@ class DeviceBuffer:
             pass
 
 
+class PinnedBuffer:
+    """Page-locked host memory (gss_host_malloc/free), handed out as NumPy views."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = max(int(nbytes), 16)
+        ptr = c_void_p()
+        ctx._check(ctx.lib.gss_host_malloc(ctx.handle, self.nbytes, ctypes.byref(ptr)),
+                   'gss_host_malloc')
+        self.ptr = ptr.value
+        self._raw = (ctypes.c_char * self.nbytes).from_address(self.ptr)
+
+    def view(self, shape, dtype, offset=0):
+        """An array of `shape` / `dtype` over the block (no copy), starting `offset` bytes in."""
+        count = int(np.prod(shape, dtype=np.int64))
+        assert offset + count * np.dtype(dtype).itemsize <= self.nbytes
+        return np.frombuffer(self._raw, dtype=dtype, count=count, offset=offset).reshape(shape)
+
+    def free(self):
+        if self.ptr is not None and self.ctx.handle is not None:
+            self._raw = None
+            self.ctx.lib.gss_host_free(self.ctx.handle, c_void_p(self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Context:
     """One per GPU (and per host thread)."""
 
@@ -237,6 +272,24 @@ class Context:
         self._check(self.lib.gss_memcpy_h2d(
             self.handle, c_void_p(buf.ptr), a.ctypes.data_as(c_void_p), a.nbytes),
             'gss_memcpy_h2d')
+
+    def pinned(self, nbytes):
+        return PinnedBuffer(self, nbytes)
+
+    def upload_async(self, buf, array, offset=0):
+        """H2D without waiting; `array` (C-contiguous, ideally a PinnedBuffer view) must stay
+        untouched until the context was synchronised."""
+        assert array.flags.c_contiguous and offset + array.nbytes <= buf.nbytes
+        self._check(self.lib.gss_memcpy_h2d_async(
+            self.handle, c_void_p(buf.ptr + offset), array.ctypes.data_as(c_void_p),
+            array.nbytes), 'gss_memcpy_h2d_async')
+
+    def download_async(self, array, buf, offset=0):
+        """D2H into `array` without waiting (valid after synchronize())."""
+        assert array.flags.c_contiguous and offset + array.nbytes <= buf.nbytes
+        self._check(self.lib.gss_memcpy_d2h_async(
+            self.handle, array.ctypes.data_as(c_void_p), c_void_p(buf.ptr + offset),
+            array.nbytes), 'gss_memcpy_d2h_async')
 
     def to_host(self, buf, shape, dtype):
         out = np.empty(shape, dtype=dtype)

@@ -218,6 +218,7 @@ class Enhancer:
     device_id: int = None
     iterator_factory: object = field(default=None, repr=False)
     inflight: int = 2        # utterances kept in flight per GPU by enhance_session
+    loaders: int = 3         # host threads that read the next examples' audio ahead of the GPU
 
     # ------------------------------------------------------------------ STFT
     def stft(self, x):
@@ -309,54 +310,204 @@ class Enhancer:
                     print('ERROR: Failed example:', ex.get('example_id'))
                     raise
             return
-        pipe = ops.UtterancePipeline(self._params(), depth=self.inflight, first_ctx=self._ctx())
-        # A loader thread reads the audio of the next examples while this thread feeds the
-        # GPU and writes results (file reads and NumPy copies release the GIL).  The samples
-        # stay 16-bit PCM on the host; the STFT kernel converts them.
-        from concurrent.futures import ThreadPoolExecutor
+        # Host side of the session (replaces core.py:363-392 + io/audioread.py): `loaders`
+        # threads prepare the next examples -- WAV slices by preadv straight into page-locked
+        # (D, N) int16 rows, activity tracks sliced into uint8 rows; no float conversion, no
+        # stacking copies (the STFT kernel converts the PCM) --, this thread starts the DMAs
+        # and the kernels (nothing in it waits for the GPU except pop()), fetches only the
+        # samples that survive the context trim, and a writer thread normalises and writes the
+        # WAV files.  File reads, memcpy and the ctypes calls release the GIL.
+        import threading
+        import time
         from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        from pb_chime5_amd.io.wav_slices import WavSliceReader
+
+        loaders = max(int(self.loaders), 1)
+        pipe = ops.UtterancePipeline(self._params(), depth=self.inflight, first_ctx=self._ctx(),
+                                     staging_sets=self.inflight + loaders + 1)
+        reader = WavSliceReader()
+        clock = self.session_clock = dict(
+            examples=0, loader_threads=loaders, wall_s=0.0, host_wait_s=0.0, enqueue_s=0.0,
+            gpu_wait_s=0.0, write_wait_s=0.0, loader_busy_s=0.0, writer_busy_s=0.0)
+        lock = threading.Lock()
+        t_begin = time.perf_counter()
 
         def prepare(ex):
-            obs, ex_array_activity, speaker_id = self._prepare_example(ex, dtype=np.int16)
-            target = tuple(ex_array_activity.keys()).index(speaker_id)
-            activity = np.array(list(ex_array_activity.values()))
-            start_ctx = end_ctx = 0
-            if self.bf_drop_context:
-                start_ctx, end_ctx = start_end_context_samples(ex)
-            return obs, activity, target, start_ctx, end_ctx
+            staging = pipe.acquire_staging()
+            if staging is None:
+                raise RuntimeError('the session was aborted')
+            t0 = time.perf_counter()
+            try:
+                meta = self._prepare_into(ex, staging, reader)
+            except BaseException:
+                pipe.release_staging(staging)
+                raise
+            with lock:
+                clock['loader_busy_s'] += time.perf_counter() - t0
+            return (staging,) + meta
 
-        loader = ThreadPoolExecutor(max_workers=1)
+        def write(ex, x_hat):
+            t0 = time.perf_counter()
+            self._write(ex, x_hat, audio_dir)
+            with lock:
+                clock['writer_busy_s'] += time.perf_counter() - t0
+
+        loader = ThreadPoolExecutor(max_workers=loaders, thread_name_prefix='gss-loader')
+        writer = ThreadPoolExecutor(max_workers=1, thread_name_prefix='gss-writer')
         ahead = deque()
+        writes = deque()
         source = iter(examples)
 
         def refill():
-            while len(ahead) < self.inflight:
+            while len(ahead) < loaders:
                 try:
                     ex = next(source)
                 except StopIteration:
                     return
                 ahead.append((ex, loader.submit(prepare, ex)))
 
+        def pop_and_write():
+            t0 = time.perf_counter()
+            done, x_hat = pipe.pop()
+            clock['gpu_wait_s'] += time.perf_counter() - t0
+            writes.append((done, writer.submit(write, done, x_hat)))
+            while len(writes) > 8 or (writes and writes[0][1].done()):
+                ex_w, fut = writes.popleft()
+                t0 = time.perf_counter()
+                try:
+                    fut.result()
+                except Exception:
+                    print('ERROR: Failed example:', ex_w.get('example_id'))
+                    raise
+                clock['write_wait_s'] += time.perf_counter() - t0
+
         try:
             refill()
             while ahead:
                 ex, future = ahead.popleft()
+                t0 = time.perf_counter()
                 try:
                     prepared = future.result()
                 except Exception:
                     print('ERROR: Failed example:', ex.get('example_id'))
                     raise
+                clock['host_wait_s'] += time.perf_counter() - t0
                 refill()
                 if pipe.full():
-                    done, x_hat = pipe.pop()
-                    self._write(done, self._trim_context(x_hat, done), audio_dir)
-                pipe.enqueue(ex, *prepared)
+                    pop_and_write()
+                t0 = time.perf_counter()
+                try:
+                    pipe.enqueue_staged(ex, *prepared)
+                except BaseException:
+                    pipe.release_staging(prepared[0])
+                    raise
+                clock['enqueue_s'] += time.perf_counter() - t0
+                clock['examples'] += 1
             while len(pipe):
-                done, x_hat = pipe.pop()
-                self._write(done, self._trim_context(x_hat, done), audio_dir)
+                pop_and_write()
+            t0 = time.perf_counter()
+            while writes:
+                ex_w, fut = writes.popleft()
+                try:
+                    fut.result()
+                except Exception:
+                    print('ERROR: Failed example:', ex_w.get('example_id'))
+                    raise
+            clock['write_wait_s'] += time.perf_counter() - t0
         finally:
+            # wake loader threads that wait for a free staging set (after an error in this
+            # thread nobody pops any more); their examples fail with the RuntimeError below
+            for _ in range(loaders):
+                pipe.release_staging(None)
             loader.shutdown(wait=True, cancel_futures=True)
+            writer.shutdown(wait=True, cancel_futures=True)
             pipe.close()
+            reader.close()
+            clock['wall_s'] = time.perf_counter() - t_begin
+
+    # -- the clock of an example: overridden by the CHiME-6 front doors (one clock for all)
+    def _audio_span(self, ex, array):
+        return ex['start']['observation'][array], ex['end']['observation'][array]
+
+    def _activity_span(self, ex):
+        """(speaker -> track, start, nominal end) of the tracks that guide this example."""
+        reference_array = self._reference_array(ex)
+        start, end = self._audio_span(ex, reference_array)
+        return self.activity[ex['session_id']][reference_array], start, end
+
+    def _keep_range(self, ex):
+        """The samples of x_hat that `_trim_context` keeps (None: all)."""
+        if self.context_samples <= 0:
+            return None
+        reference_array = self._reference_array(ex)
+        keep_from = (ex['start_orig']['observation'][reference_array]
+                     - ex['start']['observation'][reference_array])
+        return keep_from, keep_from + ex['num_samples_orig']['observation'][reference_array]
+
+    fast_loader = True      # False: always go through _prepare_example (RTTM front door)
+
+    def _prepare_into(self, ex, staging, reader):
+        """Host side of enhance_example (core.py:396-490) for the session driver: fills
+        ``staging.obs`` (D, N) int16 with the PCM samples of the selected channels (arrays cut
+        to the shortest) and ``staging.act`` (K, N_act) uint8 with the activity tracks; returns
+        (target index, start context, end context, kept sample range).  One mono file per
+        microphone (CHiME-5 / 6) is read slice by slice straight into the rows; anything else
+        goes through `_prepare_example` and one copy."""
+        speaker_id = ex['speaker_id']
+        plan = None
+        if self.fast_loader:
+            observation = ex['audio_path']['observation']
+            if self.multiarray is False:
+                arrays, select = [self._reference_array(ex)], None
+            elif self.multiarray is True:
+                arrays, select = sorted(observation.keys()), None
+            elif self.multiarray == 'outer_array_mics':
+                arrays, select = sorted(observation.keys()), (0, -1)
+            elif self.multiarray == 'first_array_mics':
+                arrays, select = sorted(observation.keys()), (0,)
+            else:
+                raise ValueError(self.multiarray)
+            plan, lengths = [], []
+            for array in arrays:
+                paths = observation[array]
+                start, stop = self._audio_span(ex, array)
+                if not isinstance(paths, (list, tuple)) or any(
+                        reader.info(p).channels != 1 for p in paths):
+                    plan = None
+                    break
+                n_array = {reader.slice_length(p, start, stop) for p in paths}
+                assert len(n_array) == 1, (array, n_array)   # np.array([...]) needs equal lengths
+                lengths.append(n_array.pop())
+                chosen = paths if select is None else [paths[i] for i in select]
+                plan.extend((p, start) for p in chosen)
+
+        if plan is None:
+            obs, ex_array_activity, _ = self._prepare_example(ex, dtype=np.int16)
+            keys = tuple(ex_array_activity.keys())
+            activity = np.array(list(ex_array_activity.values()))
+            rows, act = staging.shape(*obs.shape, *activity.shape)
+            rows[...] = obs
+            act[...] = activity != 0
+        else:
+            tracks, a, b = self._activity_span(ex)
+            keys = tuple(tracks.keys())
+            spans = [(a, min(b, len(arr))) for arr in tracks.values()]
+            n_act = {hi - lo for lo, hi in spans}
+            assert len(n_act) == 1, n_act                    # np.array(list(...)) likewise
+            rows, act = staging.shape(len(plan), min(lengths), len(keys), n_act.pop())
+            for row, (path, start) in zip(rows, plan):
+                reader.read_into(path, start, row)
+            for row, arr, (lo, hi) in zip(act, tracks.values(), spans):
+                if hasattr(arr, 'slice_into'):
+                    arr.slice_into(lo, hi, row)
+                else:
+                    row[:] = np.asarray(arr[lo:hi]) != 0
+
+        start_ctx = end_ctx = 0
+        if self.bf_drop_context:
+            start_ctx, end_ctx = start_end_context_samples(ex)
+        return keys.index(speaker_id), start_ctx, end_ctx, self._keep_range(ex)
 
     # ------------------------------------------------------------------ examples
     def enhance_example(self, ex, debug=False):

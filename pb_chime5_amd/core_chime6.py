@@ -98,6 +98,19 @@ class Enhancer(core.Enhancer):
             x_hat = x_hat[..., start_context:start_context + ex['num_samples_orig']]
         return x_hat
 
+    # the session driver's loader (core.Enhancer._prepare_into) on CHiME-6's single clock
+    def _audio_span(self, ex, array):
+        return ex['start'], ex['end']
+
+    def _activity_span(self, ex):
+        return self.activity[ex['session_id']], ex['start'], ex['end']
+
+    def _keep_range(self, ex):
+        if self.context_samples <= 0:
+            return None
+        keep_from = ex['start_orig'] - ex['start']
+        return keep_from, keep_from + ex['num_samples_orig']
+
 
 def get_enhancer(
     multiarray=False,

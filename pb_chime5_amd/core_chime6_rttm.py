@@ -99,6 +99,17 @@ class Enhancer(core.Enhancer):
             x_hat = x_hat[..., start_context:start_context + ex['num_samples_orig']]
         return x_hat
 
+    # RTTM segments may reach past the end of a recording (zero padded by
+    # recursive_load_audio) and the garbage class has no length: the session driver's loader
+    # threads go through _prepare_example above and copy once
+    fast_loader = False
+
+    def _keep_range(self, ex):
+        if self.context_samples <= 0:
+            return None
+        keep_from = ex['start_orig'] - ex['start']
+        return keep_from, keep_from + ex['num_samples_orig']
+
 
 def get_database(chime6_dir, rttm, multiarray):
     """core_chime6_rttm.py:288-357."""

@@ -164,6 +164,46 @@ extern "C" int gss_memcpy_d2h(gss_ctx *ctx, void *dst, const void *src, size_t b
     return GSS_OK;
 }
 
+// Page-locked host memory + copies that do not wait: the session driver's staging buffers.
+// WAV samples are read straight into a pinned (D, N) int16 block, one DMA brings it to the
+// device while the host thread goes on to enqueue the kernels behind it.
+extern "C" int gss_host_malloc(gss_ctx *ctx, size_t bytes, void **host_ptr) {
+    if (!ctx || !host_ptr) return GSS_ERR_INVALID;
+    GSS_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    *host_ptr = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipHostMalloc(host_ptr, bytes, hipHostMallocDefault);
+    if (e != hipSuccess)
+        return gss_fail(ctx, GSS_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes,
+                        hipGetErrorString(e));
+    return GSS_OK;
+}
+
+extern "C" int gss_host_free(gss_ctx *ctx, void *host_ptr) {
+    if (!ctx) return GSS_ERR_INVALID;
+    if (!host_ptr) return GSS_OK;
+    // no stream synchronisation here (unlike gss_dev_free): loader threads resize their
+    // staging blocks while the context's owner thread is enqueueing; the caller guarantees
+    // that no copy from / to the block is still in flight
+    GSS_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    GSS_HIP_CHECK(ctx, hipHostFree(host_ptr));
+    return GSS_OK;
+}
+
+extern "C" int gss_memcpy_h2d_async(gss_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    GSS_ENTER(ctx);
+    if (bytes == 0) return GSS_OK;
+    GSS_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return GSS_OK;
+}
+
+extern "C" int gss_memcpy_d2h_async(gss_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    GSS_ENTER(ctx);
+    if (bytes == 0) return GSS_OK;
+    GSS_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return GSS_OK;
+}
+
 extern "C" int gss_memset(gss_ctx *ctx, void *dst, int value, size_t bytes) {
     GSS_ENTER(ctx);
     if (bytes == 0) return GSS_OK;

@@ -16,7 +16,8 @@
   [UPSTREAM-RECALL libsndfile's clipping double -> short conversion].
 
 The reference uses ``soundfile`` (absent in this image); only RIFF/WAVE PCM16 --
-what CHiME-5/6 ships -- is handled here, with the standard-library ``wave``.
+what CHiME-5/6 ships -- is handled here: a small RIFF chunk walk (io/wav_slices.py, shared with
+the session driver's slice reader) for reading, the standard-library ``wave`` for writing.
 """
 import wave
 from pathlib import Path
@@ -25,16 +26,17 @@ import numpy as np
 
 
 def _load_one(path, start=None, stop=None, dtype=np.float64):
-    with wave.open(str(path), 'rb') as w:
-        if w.getsampwidth() != 2:
-            raise NotImplementedError(
-                f'{path}: only 16-bit PCM is supported, got {8 * w.getsampwidth()} bit')
-        channels = w.getnchannels()
-        total = w.getnframes()
-        start = 0 if start is None else int(start)
+    import os
+    from pb_chime5_amd.io.wav_slices import parse_wav_header
+    fd = os.open(os.fspath(path), os.O_RDONLY)
+    try:
+        offset, total, channels, _ = parse_wav_header(fd, path)   # NotImplementedError: not PCM16
+        start = 0 if start is None else min(int(start), total)
         stop = total if stop is None else min(int(stop), total)
-        w.setpos(min(start, total))
-        raw = w.readframes(max(stop - start, 0))
+        count = max(stop - start, 0)
+        raw = os.pread(fd, 2 * channels * count, offset + 2 * channels * start)
+    finally:
+        os.close(fd)
     data = np.frombuffer(raw, dtype='<i2')
     if np.dtype(dtype) != np.int16:
         data = data.astype(dtype) / 2 ** 15

@@ -372,6 +372,35 @@ class ResidentUtterance:
         return x_hat
 
 
+class HostStaging:
+    """One utterance's inputs in page-locked host memory: ``obs`` (D, N) int16 PCM followed by
+    ``act`` (K, N_act) uint8, in one block (grow-only).  Loader threads fill the rows (WAV
+    slices by preadv, activity tracks by slice_into), the feeder hands the set to
+    `UtterancePipeline.enqueue_staged`, which starts two DMAs from it."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.block = None
+        self.obs = self.act = None
+
+    def shape(self, D, N, K, N_act):
+        off = (2 * D * N + 255) // 256 * 256
+        need = off + K * N_act
+        if self.block is None or self.block.nbytes < need:
+            if self.block is not None:
+                self.block.free()
+            self.block = self.ctx.pinned(int(need * 1.25) + 4096)
+        self.obs = self.block.view((D, N), np.int16, 0)
+        self.act = self.block.view((K, N_act), np.uint8, off)
+        return self.obs, self.act
+
+    def free(self):
+        self.obs = self.act = None
+        if self.block is not None:
+            self.block.free()
+            self.block = None
+
+
 class UtterancePipeline:
     """Keeps up to ``depth`` utterances in flight on one GPU, each on its own context
     (HIP stream + workspace), so that one utterance's latency-bound kernels overlap the
@@ -389,8 +418,10 @@ class UtterancePipeline:
     Device buffers are per slot and grow-only (no hipMalloc / hipFree between
     utterances: hipFree synchronises the whole device)."""
 
-    def __init__(self, params, depth=2, device_id=None, window=None, first_ctx=None):
+    def __init__(self, params, depth=2, device_id=None, window=None, first_ctx=None,
+                 staging_sets=0):
         from collections import deque
+        import queue
         assert depth >= 1
         first = first_ctx or default_context(device_id)
         self.params = params
@@ -401,6 +432,13 @@ class UtterancePipeline:
         self._pending = deque()
         self._next = 0
         self.dropped = []       # tags close() drained without handing out their result
+        # page-locked input sets for enqueue_staged (acquire_staging blocks until one is free;
+        # a set is free again once its utterance was popped)
+        self._staging = queue.Queue()
+        self._all_staging = [HostStaging(first) for _ in range(staging_sets)]
+        for st in self._all_staging:
+            self._staging.put(st)
+        self._out_host = [None for _ in self.slots]
 
     def __len__(self):
         return len(self._pending)
@@ -439,9 +477,62 @@ class UtterancePipeline:
             c_void_p(out_d.ptr), None), 'gss_enhance_observation')
         self._pending.append((tag, slot, n_out))
 
+    # ---- page-locked staging (the session driver's path) ----------------------------
+    def acquire_staging(self, timeout=None):
+        """A free HostStaging set; blocks while all are in use (loader threads call this)."""
+        return self._staging.get(timeout=timeout)
+
+    def release_staging(self, staging):
+        self._staging.put(staging)
+
+    def enqueue_staged(self, tag, staging, target_index, start_context, end_context, keep=None):
+        """Like enqueue() for inputs sitting in a HostStaging set: two asynchronous DMAs, the
+        kernels behind them, and an asynchronous D2H of the samples ``keep = (a, b)`` of the
+        result (default: all) into page-locked memory -- the host thread does not wait for any
+        of it.  The set goes back to the free list when the utterance is popped."""
+        assert not self.full(), 'pop() the oldest utterance first'
+        slot = self._next
+        self._next = (self._next + 1) % len(self.slots)
+        ctx, p = self.slots[slot], self.params
+        obs, act = staging.obs, staging.act
+        D, N = obs.shape
+        K, N_act = act.shape
+        T = stft_frames(N, p.stft_size, p.stft_shift, p.stft_fading)
+        n_out = int(ctx.lib.gss_istft_num_samples(T, p.stft_size, p.stft_shift, p.stft_fading))
+        a, b = (0, n_out) if keep is None else (min(max(int(keep[0]), 0), n_out),
+                                                 min(max(int(keep[1]), 0), n_out))
+        b = max(a, b)
+        obs_d = self._buffer(slot, 'obs', obs.nbytes)
+        act_d = self._buffer(slot, 'act', act.nbytes)
+        out_d = self._buffer(slot, 'out', 8 * max(n_out, 1))
+        out_h = self._out_host[slot]
+        if out_h is None or out_h.nbytes < 8 * (b - a):
+            if out_h is not None:
+                out_h.free()
+            out_h = self._out_host[slot] = ctx.pinned(int(8 * (b - a) * 1.25) + 4096)
+        out_view = out_h.view((b - a,), np.float64)
+        ctx.upload_async(obs_d, obs)
+        ctx.upload_async(act_d, act)
+        ctx._check(ctx.lib.gss_enhance_observation_pcm16(
+            ctx.handle, ctypes.byref(p), c_void_p(obs_d.ptr), D, N, c_void_p(act_d.ptr), K,
+            N_act, int(target_index), int(start_context), int(end_context),
+            c_void_p(out_d.ptr), None), 'gss_enhance_observation')
+        if b > a:
+            ctx.download_async(out_view, out_d, offset=8 * a)
+        self._pending.append((tag, slot, n_out, staging, out_view))
+
     def pop(self):
-        tag, slot, n_out = self._pending.popleft()
-        x_hat = self.slots[slot].to_host(self._bufs[slot]['out'], (n_out,), np.float64)
+        entry = self._pending.popleft()
+        tag, slot, n_out = entry[:3]
+        if len(entry) == 5:
+            staging, out_view = entry[3:]
+            try:
+                self.slots[slot].synchronize()
+                x_hat = out_view.copy()      # the slot's pinned block is reused by the next one
+            finally:
+                self.release_staging(staging)
+        else:
+            x_hat = self.slots[slot].to_host(self._bufs[slot]['out'], (n_out,), np.float64)
         if self.params.bf in (_BF_CODES['mvdrSouden_ban'], _BF_CODES['gev_ban']):
             # what the reference raises for this utterance (raised explicitly: an `assert`
             # statement disappears under python -O and NaN audio would be written silently);
@@ -460,7 +551,7 @@ class UtterancePipeline:
         (`Enhancer._enhance_and_write` does); `self.dropped` lists the tags close() drained."""
         try:
             while self._pending:
-                tag, slot, _ = self._pending.popleft()
+                tag, slot = self._pending.popleft()[:2]
                 self.dropped.append(tag)
                 try:
                     self.slots[slot].synchronize()
@@ -468,6 +559,12 @@ class UtterancePipeline:
                     pass
         finally:
             self._bufs = [dict() for _ in self.slots]
+            for block in self._all_staging + [h for h in self._out_host if h is not None]:
+                try:
+                    block.free()
+                except Exception:
+                    pass
+            self._all_staging, self._out_host = [], [None for _ in self.slots]
             for c in self.slots[1:]:
                 try:
                     c.close()

@@ -76,6 +76,16 @@ def write_chime5_corpus(root, session_id='S02', seconds=10.0, seed=11, utts_per_
     for d, (a, m) in enumerate(channels):
         dump_audio(obs[d], audio_dir / f'{session_id}_{a}.CH{m}.wav', normalize=False)
 
+    return _write_json(root, rng, session_id, utterances, n_total, audio_dir, chime6)
+
+
+def _write_json(root, rng, session_id, utterances, n_total, audio_dir, chime6):
+    """The example JSON for `utterances` [(speaker, start, end, words) on the 'original' clock]:
+    per-array / per-worn-microphone clocks with an offset and a per-utterance jitter."""
+    root = Path(root)
+    dataset = mapping.session_to_dataset[session_id]
+    speakers = mapping.session_to_speakers[session_id]
+    arrays = mapping.session_to_arrays[session_id]
     audio_path = {
         'observation': {a: [str(audio_dir / f'{session_id}_{a}.CH{m}.wav') for m in range(1, 5)]
                         for a in arrays},
@@ -122,3 +132,56 @@ def write_chime5_corpus(root, session_id='S02', seconds=10.0, seed=11, utts_per_
     with open(json_path, 'w') as fd:
         json.dump(database, fd, indent=1, sort_keys=True)
     return json_path
+
+
+def write_dev_shaped_session(root, session_id='S02', seconds=660.0, num_utterances=220, seed=4,
+                             rir_taps=512, block=1 << 18):
+    """A session at the size the CHiME-5 dev set has per utterance (BASELINE.json configs[3]
+    stand-in; the corpus itself is not available): 6 arrays x 4 per-channel PCM16 files of
+    `seconds` of audio, `num_utterances` utterances whose lengths follow the dev-shaped draw of
+    synthetic.config3_core_samples (~ LogNormal(ln 2.5 s, 0.7) clipped to [0.5 s, 15 s]),
+    speakers talking over each other as at a dinner party.  Same JSON layout as
+    write_chime5_corpus.  The audio is synthesised block-wise (overlap-add of the reverberated
+    sources, one batched FFT per block) straight into int16, so that ten minutes x 24 channels
+    take seconds and ~0.5 GB instead of minutes and several GB."""
+    import scipy.fft as sfft
+    from pb_chime5_amd.synthetic import config3_core_samples
+    root = Path(root)
+    rng = np.random.default_rng(seed)
+    dataset = mapping.session_to_dataset[session_id]
+    speakers = mapping.session_to_speakers[session_id]
+    arrays = mapping.session_to_arrays[session_id]
+    n_total = int(seconds * SAMPLE_RATE)
+    audio_dir = root / 'audio' / dataset
+    audio_dir.mkdir(parents=True, exist_ok=True)
+
+    utterances = []
+    for i in range(num_utterances):
+        spk = speakers[i % len(speakers)]
+        length = min(config3_core_samples(seed * 100000 + i), n_total // 4)
+        start = int(rng.integers(SAMPLE_RATE // 2, n_total - length - SAMPLE_RATE // 2))
+        utterances.append((spk, start, start + length, 'some words'))
+    utterances.sort(key=lambda u: (u[1], u[0]))
+
+    channels = [(a, m) for a in arrays for m in range(1, 5)]
+    D, S = len(channels), len(speakers)
+    acts = np.zeros((S, n_total), dtype=bool)
+    for spk, a, b, _ in utterances:
+        acts[speakers.index(spk), a:b] = True
+    sources = np.stack([_source(rng, n_total) for _ in range(S)]) * acts
+    nfft = sfft.next_fast_len(block + rir_taps - 1, real=True)
+    H = sfft.rfft(np.stack([[_rir(rng, rir_taps) for _ in range(D)] for _ in range(S)]),
+                  nfft, axis=-1, workers=-1)                                   # (S, D, nf)
+    pcm = np.empty((D, n_total), dtype=np.int16)
+    tail = np.zeros((D, rir_taps - 1))
+    for b0 in range(0, n_total, block):
+        nb = min(block, n_total - b0)
+        X = sfft.rfft(sources[:, b0:b0 + nb], nfft, axis=-1, workers=-1)        # (S, nf)
+        y = sfft.irfft(np.einsum('sf,sdf->df', X, H), nfft, axis=-1, workers=-1)
+        y[:, :rir_taps - 1] += tail
+        tail = y[:, nb:nb + rir_taps - 1].copy()
+        y = y[:, :nb] + rng.standard_normal((D, nb)) * 3e-2                    # sensor noise
+        pcm[:, b0:b0 + nb] = np.clip(np.rint(y * (0.03 * 32768)), -32768, 32767)
+    for d, (a, m) in enumerate(channels):
+        dump_audio(pcm[d], audio_dir / f'{session_id}_{a}.CH{m}.wav', normalize=False)
+    return _write_json(root, rng, session_id, utterances, n_total, audio_dir, False)

@@ -121,11 +121,31 @@ class ArrayIntervall:
         else:
             raise NotImplementedError(value)
 
+    def _bounds(self):
+        """The normalised intervals as two sorted int64 arrays, kept until the next mutation
+        (a session track holds thousands of intervals and is sliced once per utterance and
+        speaker: the slice below touches only the intervals that reach into it)."""
+        cache = self.__dict__.get('_bounds_cache')
+        if cache is None or cache[0] is not self._intervals:
+            iv = self.normalized_intervals
+            b = np.array(iv, dtype=np.int64).reshape(-1, 2)
+            cache = self._bounds_cache = (self._intervals, b[:, 0].copy(), b[:, 1].copy())
+        return cache[1], cache[2]
+
+    def slice_into(self, start, stop, out):
+        """``out[:] = self[start:stop]`` for a preallocated bool / uint8 vector (0 / 1)."""
+        start, stop = self._parse_item(slice(start, stop))
+        assert out.shape == (stop - start,), (out.shape, start, stop)
+        out[:] = 0
+        starts, ends = self._bounds()
+        lo = int(np.searchsorted(ends, start, side='right'))      # first interval ending after start
+        hi = int(np.searchsorted(starts, stop, side='left'))      # first interval starting at / after stop
+        for i in range(lo, hi):
+            s, e = max(int(starts[i]), start), min(int(ends[i]), stop)
+            if s < e:
+                out[s - start:e - start] = 1
+        return out
+
     def __getitem__(self, item):
         start, stop = self._parse_item(item)
-        arr = np.zeros(stop - start, dtype=bool)
-        for s, e in self.normalized_intervals:
-            s, e = max(s, start), min(e, stop)
-            if s < e:
-                arr[s - start:e - start] = True
-        return arr
+        return self.slice_into(start, stop, np.empty(stop - start, dtype=bool))

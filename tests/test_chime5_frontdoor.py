@@ -265,6 +265,52 @@ def test_pipelined_session_equals_sequential(corpus, fixture, tmp_path):
     assert files == sorted(p.relative_to(b) for p in b.rglob('*.wav'))
     for rel in files:
         assert (a / rel).read_bytes() == (b / rel).read_bytes(), rel
+    # where the host thread of the pipelined session spent its time (bench.py --config 4s)
+    clock = pipe.session_clock
+    assert clock['examples'] == len(files) and clock['wall_s'] > 0
+    assert clock['gpu_wait_s'] + clock['host_wait_s'] + clock['enqueue_s'] <= clock['wall_s']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('multiarray,loaders,inflight', [
+    (True, 1, 2), (True, 4, 3), ('outer_array_mics', 3, 2), ('first_array_mics', 2, 2), (False, 3, 2)])
+def test_loader_pool_session_is_byte_identical(corpus, fixture, tmp_path, multiarray, loaders,
+                                               inflight):
+    """The session driver's host side -- loader threads reading WAV slices straight into
+    page-locked int16 rows, asynchronous H2D / D2H of the trimmed range, a writer thread --
+    against the reference-shaped loop (load_audio -> float64 -> enhance_example -> dump_audio,
+    core.py:363-392): every WAV byte-identical, for every channel selection and any number of
+    loader threads / utterances in flight."""
+    a, b = tmp_path / 'seq', tmp_path / 'pool'
+    kw = dict(multiarray=multiarray, wpe_tabs=2, bss_iterations=3)
+    seq = _enhancer(corpus, fixture, **kw)
+    seq.inflight = 1
+    seq.enhance_session('S02', a, dataset_slice=slice(0, 7))
+    pool = _enhancer(corpus, fixture, **kw)
+    pool.inflight, pool.loaders = inflight, loaders
+    pool.enhance_session('S02', b, dataset_slice=slice(0, 7))
+    files = sorted(p.relative_to(a) for p in a.rglob('*.wav'))
+    assert len(files) == 7 and files == sorted(p.relative_to(b) for p in b.rglob('*.wav'))
+    for rel in files:
+        assert (a / rel).read_bytes() == (b / rel).read_bytes(), rel
+    assert pool.session_clock['loader_threads'] == loaders
+
+
+@pytest.mark.gpu
+def test_session_error_in_a_loader_thread_surfaces_and_does_not_hang(corpus, fixture, tmp_path):
+    """A missing channel file: the reference dies in its load loop with the library's error;
+    here the loader thread's exception reaches the caller (example named on stdout), the other
+    threads are released and nothing is left in flight."""
+    import copy
+    enh = _enhancer(corpus, fixture, multiarray=True, wpe=False, bss_iterations=2)
+    enh.loaders = 3
+    examples = [copy.deepcopy(ex) for ex in list(enh.get_iterator('S02'))[:6]]
+    array = sorted(examples[3]['audio_path']['observation'])[0]
+    examples[3]['audio_path']['observation'][array][1] = str(tmp_path / 'missing.wav')
+    (tmp_path / 'out' / 'dev').mkdir(parents=True)
+    with pytest.raises(FileNotFoundError):
+        enh._enhance_and_write(examples, tmp_path / 'out')
+    assert len(list((tmp_path / 'out' / 'dev').glob('*.wav'))) <= 3
 
 
 # ---------------------------------------------------------------- command line
