@@ -142,11 +142,15 @@ struct CorrTile {
 // tiles on the edge of n (240 = 7.5 x 32) the half that lies outside, which removes
 // 15 % of the MFMAs at taps * D = 240.  The host sorts the tile list by mask so that the
 // four waves of a workgroup carry similar loads.
-template <int TS, bool M3, int MASK, int NW>
-__device__ __forceinline__ void corr_tile_body(
-    const cplx *__restrict__ Yf, const double *__restrict__ wf, int64_t T, int D, int n, int c,
-    int frames_lds, cplx *S, double *wS, const CorrTile tl, bool active, int f,
-    cplx *__restrict__ R, cplx *__restrict__ P) {
+// The MFMAs of one staged chunk (CORR_KT frames = CORR_KT / 4 k-steps) of a wave's tile:
+// S = the chunk's window (frame kf of the chunk at S + kf * D), wS = its CORR_KT weights.
+// 3M complex product: with t1 = sum ar br, t2 = sum ai bi, t3 = sum (ar+ai)(br-bi)
+//   re(a conj b) = t1 + t2,   im(a conj b) = t3 - t1 + t2
+// -- three real MFMAs per tile and k-step instead of four.
+template <int TS, bool M3, int MASK>
+__device__ __forceinline__ void corr_chunk(const cplx *S, const double *wS, int D,
+                                           const CorrTile &tl, v4d (&t1)[TS][TS],
+                                           v4d (&t2)[TS][TS], v4d (&t3)[TS][TS]) {
     const int lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
     auto need = [](int a, int b) { return ((MASK >> (a * TS + b)) & 1) != 0; };
@@ -160,10 +164,127 @@ __device__ __forceinline__ void corr_tile_body(
         for (int a = 0; a < TS; ++a) r = r || need(a, b);
         return r;
     };
-    // 3M complex product: with t1 = sum ar br, t2 = sum ai bi, t3 = sum (ar+ai)(br-bi)
-    //   re(a conj b) = t1 + t2,   im(a conj b) = t3 - t1 + t2
-    // -- three real MFMAs per tile and k-step instead of four.
-    v4d t1[TS][TS], t2[TS][TS], t3[TS][TS];
+    const int ksteps = CORR_KT / 4;
+    // operands of k-step ks+1 are fetched from LDS while the MFMAs of ks run
+    cplx a_cur[TS], b_cur[TS], a_nxt[TS], b_nxt[TS];
+    double w_cur, w_nxt = 0.0;
+    {
+        const cplx *base = S + lk * D + li;
+        w_cur = wS[lk];
+#pragma unroll
+        for (int m = 0; m < TS; ++m) {
+            a_cur[m] = base[tl.row_off + 16 * m];
+            b_cur[m] = base[tl.col_off + 16 * m];
+        }
+    }
+    // (one-sub-tile waves are not unrolled all the way: hoisting 16 k-steps of operand
+    // loads costs the registers that let a fourth and fifth wave share the SIMD)
+    constexpr int KU = TS == 1 ? 4 : 16;
+#pragma unroll KU
+    for (int ks = 0; ks < ksteps; ++ks) {
+        if (ks + 1 < ksteps) {
+            const int kf = 4 * (ks + 1) + lk;
+            const cplx *base = S + kf * D + li;
+            w_nxt = wS[kf];
+#pragma unroll
+            for (int m = 0; m < TS; ++m) {
+                a_nxt[m] = need_row(m) ? base[tl.row_off + 16 * m] : c_make(0.0, 0.0);
+                b_nxt[m] = need_col(m) ? base[tl.col_off + 16 * m] : c_make(0.0, 0.0);
+            }
+        }
+        double ar[TS], ai[TS], as[TS], br[TS], bi[TS], bd[TS];
+#pragma unroll
+        for (int m = 0; m < TS; ++m) {
+#ifdef GSS_EXP_NOVALU       // timing-only ablation (tools/wpe_kprof.py): no operand arithmetic
+            ar[m] = a_cur[m].x;
+            ai[m] = a_cur[m].y;
+            as[m] = a_cur[m].x;
+            br[m] = b_cur[m].x;
+            bi[m] = b_cur[m].y;
+            bd[m] = b_cur[m].y;
+#else
+            ar[m] = a_cur[m].x * w_cur;
+            ai[m] = a_cur[m].y * w_cur;
+            as[m] = ar[m] + ai[m];
+            br[m] = b_cur[m].x;
+            bi[m] = b_cur[m].y;
+            bd[m] = b_cur[m].x - b_cur[m].y;
+#endif
+        }
+        if (M3) {
+#pragma unroll
+            for (int a = 0; a < TS; ++a)
+#pragma unroll
+                for (int b = 0; b < TS; ++b) {
+                    if (!need(a, b)) continue;
+                    t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], br[b], t1[a][b], 0, 0, 0);
+                    t2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], bi[b], t2[a][b], 0, 0, 0);
+                    t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[a], bd[b], t3[a][b], 0, 0, 0);
+                }
+        } else {
+            // 4M: t1 = re, t3 = im  (t2 unused)
+#pragma unroll
+            for (int a = 0; a < TS; ++a)
+#pragma unroll
+                for (int b = 0; b < TS; ++b) {
+                    if (!need(a, b)) continue;
+                    t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], br[b], t1[a][b], 0, 0, 0);
+                    t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], br[b], t3[a][b], 0, 0, 0);
+                }
+#pragma unroll
+            for (int a = 0; a < TS; ++a)
+#pragma unroll
+                for (int b = 0; b < TS; ++b) {
+                    if (!need(a, b)) continue;
+                    t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], bi[b], t1[a][b], 0, 0, 0);
+                    t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], -bi[b], t3[a][b], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < TS; ++m) {
+            a_cur[m] = a_nxt[m];
+            b_cur[m] = b_nxt[m];
+        }
+        w_cur = w_nxt;
+    }
+}
+
+// The finished tile of a wave -> R (upper tiles) or P.
+// C/D fragment of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+template <int TS, bool M3, int MASK>
+__device__ __forceinline__ void corr_store(const CorrTile &tl, int f, int n, int c, int D,
+                                           const v4d (&t1)[TS][TS], const v4d (&t2)[TS][TS],
+                                           const v4d (&t3)[TS][TS], cplx *__restrict__ R,
+                                           cplx *__restrict__ P) {
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    auto need = [](int a, int b) { return ((MASK >> (a * TS + b)) & 1) != 0; };
+    cplx *Rf = R + (int64_t)f * n * n;
+    cplx *Pf = P + (int64_t)f * n * D;
+#pragma unroll
+    for (int a = 0; a < TS; ++a)
+#pragma unroll
+        for (int b = 0; b < TS; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                if (!need(a, b)) continue;
+                const int r = tl.row_off + 16 * a + lk + 4 * reg;
+                const int cc = tl.col_off + 16 * b + li;
+                const cplx v = M3 ? c_make(t1[a][b][reg] + t2[a][b][reg],
+                                           (t3[a][b][reg] - t1[a][b][reg]) + t2[a][b][reg])
+                                  : c_make(t1[a][b][reg], t3[a][b][reg]);
+                if (r >= n) continue;
+                if (tl.is_p) {
+                    const int d = cc - c * D;
+                    if (d >= 0 && d < D) Pf[r * D + d] = v;
+                } else if (cc < n) {
+                    Rf[r * n + cc] = v;
+                }
+            }
+}
+
+template <int TS>
+__device__ __forceinline__ void corr_zero(v4d (&t1)[TS][TS], v4d (&t2)[TS][TS], v4d (&t3)[TS][TS]) {
 #pragma unroll
     for (int a = 0; a < TS; ++a)
 #pragma unroll
@@ -172,6 +293,15 @@ __device__ __forceinline__ void corr_tile_body(
             t2[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
             t3[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
         }
+}
+
+template <int TS, bool M3, int MASK, int NW>
+__device__ __forceinline__ void corr_tile_body(
+    const cplx *__restrict__ Yf, const double *__restrict__ wf, int64_t T, int D, int n, int c,
+    int frames_lds, cplx *S, double *wS, const CorrTile tl, bool active, int f,
+    cplx *__restrict__ R, cplx *__restrict__ P) {
+    v4d t1[TS][TS], t2[TS][TS], t3[TS][TS];
+    corr_zero<TS>(t1, t2, t3);
 
     // The window of chunk i+1 is fetched from global memory into registers before the
     // MFMAs of chunk i are issued and written to LDS after them, so the global-load
@@ -215,106 +345,9 @@ __device__ __forceinline__ void corr_tile_body(
         stage_store(t0);
         __syncthreads();
         if (t0 + CORR_KT < T) stage_load(t0 + CORR_KT);
-        if (!active) continue;
-        const int ksteps = CORR_KT / 4;
-        // operands of k-step ks+1 are fetched from LDS while the MFMAs of ks run
-        cplx a_cur[TS], b_cur[TS], a_nxt[TS], b_nxt[TS];
-        double w_cur, w_nxt = 0.0;
-        {
-            const cplx *base = S + lk * D + li;
-            w_cur = wS[lk];
-#pragma unroll
-            for (int m = 0; m < TS; ++m) {
-                a_cur[m] = base[tl.row_off + 16 * m];
-                b_cur[m] = base[tl.col_off + 16 * m];
-            }
-        }
-        // (one-sub-tile waves are not unrolled all the way: hoisting 16 k-steps of operand
-        // loads costs the registers that let a fourth and fifth wave share the SIMD)
-        constexpr int KU = TS == 1 ? 4 : 16;
-#pragma unroll KU
-        for (int ks = 0; ks < ksteps; ++ks) {
-            if (ks + 1 < ksteps) {
-                const int kf = 4 * (ks + 1) + lk;
-                const cplx *base = S + kf * D + li;
-                w_nxt = wS[kf];
-#pragma unroll
-                for (int m = 0; m < TS; ++m) {
-                    a_nxt[m] = need_row(m) ? base[tl.row_off + 16 * m] : c_make(0.0, 0.0);
-                    b_nxt[m] = need_col(m) ? base[tl.col_off + 16 * m] : c_make(0.0, 0.0);
-                }
-            }
-            double ar[TS], ai[TS], as[TS], br[TS], bi[TS], bd[TS];
-#pragma unroll
-            for (int m = 0; m < TS; ++m) {
-                ar[m] = a_cur[m].x * w_cur;
-                ai[m] = a_cur[m].y * w_cur;
-                as[m] = ar[m] + ai[m];
-                br[m] = b_cur[m].x;
-                bi[m] = b_cur[m].y;
-                bd[m] = b_cur[m].x - b_cur[m].y;
-            }
-            if (M3) {
-#pragma unroll
-                for (int a = 0; a < TS; ++a)
-#pragma unroll
-                    for (int b = 0; b < TS; ++b) {
-                        if (!need(a, b)) continue;
-                        t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], br[b], t1[a][b], 0, 0, 0);
-                        t2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], bi[b], t2[a][b], 0, 0, 0);
-                        t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[a], bd[b], t3[a][b], 0, 0, 0);
-                    }
-            } else {
-                // 4M: t1 = re, t3 = im  (t2 unused)
-#pragma unroll
-                for (int a = 0; a < TS; ++a)
-#pragma unroll
-                    for (int b = 0; b < TS; ++b) {
-                        if (!need(a, b)) continue;
-                        t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], br[b], t1[a][b], 0, 0, 0);
-                        t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], br[b], t3[a][b], 0, 0, 0);
-                    }
-#pragma unroll
-                for (int a = 0; a < TS; ++a)
-#pragma unroll
-                    for (int b = 0; b < TS; ++b) {
-                        if (!need(a, b)) continue;
-                        t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], bi[b], t1[a][b], 0, 0, 0);
-                        t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], -bi[b], t3[a][b], 0, 0, 0);
-                    }
-            }
-#pragma unroll
-            for (int m = 0; m < TS; ++m) {
-                a_cur[m] = a_nxt[m];
-                b_cur[m] = b_nxt[m];
-            }
-            w_cur = w_nxt;
-        }
+        if (active) corr_chunk<TS, M3, MASK>(S, wS, D, tl, t1, t2, t3);
     }
-    if (!active) return;
-    // C/D fragment of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-    cplx *Rf = R + (int64_t)f * n * n;
-    cplx *Pf = P + (int64_t)f * n * D;
-#pragma unroll
-    for (int a = 0; a < TS; ++a)
-#pragma unroll
-        for (int b = 0; b < TS; ++b)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                if (!need(a, b)) continue;
-                const int r = tl.row_off + 16 * a + lk + 4 * reg;
-                const int cc = tl.col_off + 16 * b + li;
-                const cplx v = M3 ? c_make(t1[a][b][reg] + t2[a][b][reg],
-                                           (t3[a][b][reg] - t1[a][b][reg]) + t2[a][b][reg])
-                                  : c_make(t1[a][b][reg], t3[a][b][reg]);
-                if (r >= n) continue;
-                if (tl.is_p) {
-                    const int d = cc - c * D;
-                    if (d >= 0 && d < D) Pf[r * D + d] = v;
-                } else if (cc < n) {
-                    Rf[r * n + cc] = v;
-                }
-            }
+    if (active) corr_store<TS, M3, MASK>(tl, f, n, c, D, t1, t2, t3, R, P);
 }
 
 template <int TS, bool M3, int NW>
@@ -352,6 +385,339 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_kernel(
         corr_tile_body<TS, M3, FULL, NW>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P);
     }
 #undef CORR_CASE
+}
+
+// ---- the same tiles with the window brought in by LDS-DMA (`buffer_load_dwordx4 ... lds`)
+// Why: on MI355X the f64 MFMA runs on the f64 vector lanes (matrix peak = vector peak), so
+// every VALU instruction a wave issues -- the index arithmetic, bounds selects and the
+// register -> LDS pass of the staged window above are ~200 of them per 64-frame chunk, next
+// to 128 f64 operand multiplications -- is time the SIMD does not spend on the 192 MFMAs of
+// that chunk.  The window of a chunk is one contiguous run of the frequency's flat (T, D)
+// slab, which is exactly what LDS-DMA copies: a wave instruction moves 64 consecutive
+// complex values (1 KiB) to a wave-uniform LDS base + 16 * lane; the buffer resource is
+// sized to the slab, so the elements past the last frame arrive as zeros without a compare.
+// No staging registers, no ds_write pass, one v_add per piece; two LDS windows alternate so
+// that the DMA of chunk i + 1 is in flight during the MFMAs of chunk i and ONE barrier per
+// chunk remains.  (Frames before the first one -- only while t0 < c -- are the lanes of a
+// piece with a negative element index: they store a zero to their slot instead.)
+using lds_void_ptr = __attribute__((address_space(3))) void *;
+
+#ifdef GSS_CORR_TRACE
+// tools/corr_trace.py: per workgroup {block, start, first window landed, loop done, stored,
+// HW_ID} on the 100 MHz wall clock (build with tools/build_variant.sh NAME -DGSS_CORR_TRACE=1)
+__device__ long long g_corr_trace[8192 * 6];
+__device__ long long g_corr_phase[8192 * 4];     // persistent kernel, wave 0: cycles per phase
+extern "C" int gss_debug_corr_trace(long long *host, int entries) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_corr_trace), sizeof(long long) * 6 * entries);
+}
+extern "C" int gss_debug_corr_phase(long long *host, int entries, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_corr_phase), sizeof(long long) * 4 * entries);
+    if (reset) {
+        void *p = nullptr;
+        (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_corr_phase));
+        (void)hipMemset(p, 0, sizeof(long long) * 4 * 8192);
+    }
+    return rc;
+}
+#define CORR_TRACE(slot)                                                                  \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_corr_trace[blockIdx.x * 6 + (slot)] = wall_clock64()
+#else
+#define CORR_TRACE(slot)
+#endif
+
+template <bool M3, int MASK, int NW>
+__device__ __forceinline__ void corr_tile_body_dma(
+    const __amdgpu_buffer_rsrc_t rsrc_y, const __amdgpu_buffer_rsrc_t rsrc_w, int64_t T, int D,
+    int n, int c, int pieces, cplx *S0, double *w0, const CorrTile tl, bool active, int f,
+    cplx *__restrict__ R, cplx *__restrict__ P) {
+    constexpr int TS = 2;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int win = pieces * 64;                       // elements per LDS window
+    v4d t1[TS][TS], t2[TS][TS], t3[TS][TS];
+    corr_zero<TS>(t1, t2, t3);
+
+    auto issue = [&](int64_t t0, int b) {
+        cplx *Sb = S0 + b * win;
+        const int64_t g0 = (t0 - c) * (int64_t)D;      // slab index of the window's first element
+        for (int p = wave; p < pieces; p += NW) {
+            const int64_t gp = g0 + p * 64;            // wave-uniform
+            const uint32_t voff = (uint32_t)((gp + lane) * 16);
+            if (gp >= 0) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_void_ptr)(Sb + p * 64), 16,
+                                                         voff, 0, 0, 0);
+            } else if (gp + lane < 0) {
+                Sb[p * 64 + lane] = c_make(0.0, 0.0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_void_ptr)(Sb + p * 64), 16,
+                                                         voff, 0, 0, 0);
+            }
+        }
+        // the CORR_KT weights of the chunk: 32 lanes x 2 doubles
+        if (wave == NW - 1 && lane < CORR_KT / 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void_ptr)(w0 + b * CORR_KT), 16,
+                                                     (uint32_t)((t0 + 2 * lane) * 8), 0, 0, 0);
+    };
+    issue(0, 0);
+    __syncthreads();
+    CORR_TRACE(2);
+    int b = 0;
+    for (int64_t t0 = 0; t0 < T; t0 += CORR_KT, b ^= 1) {
+        if (t0 + CORR_KT < T) issue(t0 + CORR_KT, b ^ 1);
+        if (active) corr_chunk<TS, M3, MASK>(S0 + b * win, w0 + b * CORR_KT, D, tl, t1, t2, t3);
+        __syncthreads();       // window b ^ 1 has landed (vmcnt(0) of every wave) and b is free
+    }
+    CORR_TRACE(3);
+    if (active) corr_store<TS, M3, MASK>(tl, f, n, c, D, t1, t2, t3, R, P);
+    CORR_TRACE(4);
+}
+
+template <bool M3, int NW>
+__global__ __launch_bounds__(64 * NW) void wpe_corr_dma_kernel(
+    const cplx *__restrict__ Y, const double *__restrict__ w, int F, int64_t T, int D, int n,
+    int c, int pieces, const CorrTile *__restrict__ tiles, int ntiles, cplx *__restrict__ R,
+    cplx *__restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx *S0 = reinterpret_cast<cplx *>(smem);                       // 2 x pieces * 64
+    double *w0 = reinterpret_cast<double *>(S0 + 2 * pieces * 64);   // 2 x CORR_KT
+
+    int f, grp;
+    if (!xcd_group_map((ntiles + NW - 1) / NW, F, f, grp)) return;
+    CORR_TRACE(1);
+#ifdef GSS_CORR_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        g_corr_trace[blockIdx.x * 6 + 0] = grp;
+        g_corr_trace[blockIdx.x * 6 + 5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    }
+#endif
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile_id = grp * NW + wave;
+    const bool active = tile_id < ntiles;
+    const CorrTile tl = tiles[active ? tile_id : 0];
+    // raw buffer resources (stride 0, range check against the byte count): the frequency's
+    // (T, D) slab and its T weights
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<cplx *>(Y + (int64_t)f * T * D), 0, (int)(T * D * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(w + (int64_t)f * T), 0, (int)(T * 8), 0x00020000);
+    const int mask = __builtin_amdgcn_readfirstlane(active ? tl.mask : 1);
+#define CORR_CASE(M) \
+    case M: corr_tile_body_dma<M3, M, NW>(rsrc_y, rsrc_w, T, D, n, c, pieces, S0, w0, tl, active, f, R, P); break
+    switch (mask) {
+        CORR_CASE(1);
+        CORR_CASE(3);
+        CORR_CASE(5);
+        CORR_CASE(11);
+        default:
+            corr_tile_body_dma<M3, 15, NW>(rsrc_y, rsrc_w, T, D, n, c, pieces, S0, w0, tl, active, f, R, P);
+    }
+#undef CORR_CASE
+}
+
+// ---- persistent form: resident workgroups pull (frequency, tile group) items from queues
+// What the workgroup timeline of the one-workgroup-per-item launch shows (tools/corr_trace.py,
+// config 2: 5643 items of ~175 us on 512 resident slots): 10 % of the slot time is the tail of
+// the launch (items are 1/11 of a slot's whole share, so the slots run dry over the last ~1.7
+// item lengths), 3.6 % the gap between an item's end and the dispatch of the next workgroup
+// into its slot, 2 % the first window of every item arriving from memory with nothing to do.
+// Here the launch is `slots` workgroups that stay resident and take items from per-XCD queues
+// (a frequency's items stay on the XCD whose L2 holds its slab; an empty queue steals from the
+// next XCD's): the heavy tile groups of all frequencies first, the light ones (fewer needed
+// 16 x 16 sub-tiles per wave) last, so that the launch ends on short items; the window DMA
+// runs on across items -- the first window of item i + 1 is requested during the last chunk of
+// item i -- and the next item's index is fetched (one returning atomic by one thread) two
+// items ahead.
+struct CorrQueue {
+    int ngroups, gh;      // tile groups per frequency; the first gh are "heavy"
+};
+
+__device__ __forceinline__ int corr_queue_len(int F, int x) { return (F - x + 7) / 8; }
+
+// item q of queue x -> f * 4096 + group
+__device__ __forceinline__ int corr_queue_item(int F, int x, int q, const CorrQueue cq) {
+    const int nf = corr_queue_len(F, x);
+    const int heavy = nf * cq.gh;
+    if (q < heavy) return (x + 8 * (q / cq.gh)) * 4096 + q % cq.gh;
+    q -= heavy;
+    const int gl = max(cq.ngroups - cq.gh, 1);
+    return (x + 8 * (q / gl)) * 4096 + cq.gh + q % gl;
+}
+
+// next item for this workgroup (thread 0 only): own XCD's queue first, then the others;
+// -1 when every queue is drained.  `live` remembers the first queue that may still hold work.
+__device__ __forceinline__ int corr_fetch(int *counters, int F, int xcd, int &live, const CorrQueue cq) {
+    for (; live < 8; ++live) {
+        const int x = (xcd + live) & 7;
+        const int len = corr_queue_len(F, x) * cq.ngroups;
+        const int q = atomicAdd(counters + 16 * x, 1);
+        if (q < len) return corr_queue_item(F, x, q, cq);
+    }
+    return -1;
+}
+
+template <bool M3, int MASK, int NW, class Issue>
+__device__ __forceinline__ void corr_item_dma(
+    int64_t T, int D, int n, int c, int win, cplx *S0, double *w0, const CorrTile tl, bool active,
+    int f, int f_next, int &b, Issue &issue, int *ring_slot, int fetched, cplx *__restrict__ R,
+    cplx *__restrict__ P) {
+    constexpr int TS = 2;
+    v4d t1[TS][TS], t2[TS][TS], t3[TS][TS];
+    corr_zero<TS>(t1, t2, t3);
+    for (int64_t t0 = 0; t0 < T; t0 += CORR_KT, b ^= 1) {
+#ifdef GSS_CORR_TRACE
+        const long long ta = clock64();
+#endif
+#ifdef GSS_EXP_NODMA        // timing-only ablation: no window after the first
+        if (t0 == 0 && f_next == -2)
+#endif
+        if (t0 + CORR_KT < T)
+            issue(f, t0 + CORR_KT, b ^ 1);
+        else if (f_next >= 0)
+            issue(f_next, 0, b ^ 1);          // the next item's first window
+#ifdef GSS_CORR_TRACE
+        const long long tb = clock64();
+#endif
+        if (active) corr_chunk<TS, M3, MASK>(S0 + b * win, w0 + b * CORR_KT, D, tl, t1, t2, t3);
+        // the item fetched at the start of this one (its atomic has had a chunk to return):
+        // into the ring slot of the previous item, published by the barrier below
+        if (t0 == 0 && threadIdx.x == 0) *ring_slot = fetched;
+#ifdef GSS_CORR_TRACE
+        const long long tc = clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long td = clock64();
+#endif
+        __syncthreads();       // window b ^ 1 has landed (vmcnt(0) of every wave) and b is free
+#ifdef GSS_CORR_TRACE
+        if (threadIdx.x == 0 && blockIdx.x < 8192) {
+            const long long te = clock64();
+            g_corr_phase[blockIdx.x * 4 + 0] += tb - ta;     // issue
+            g_corr_phase[blockIdx.x * 4 + 1] += tc - tb;     // MFMA chunk
+            g_corr_phase[blockIdx.x * 4 + 2] += td - tc;     // waiting for the DMA
+            g_corr_phase[blockIdx.x * 4 + 3] += te - td;     // barrier
+        }
+#endif
+    }
+#ifdef GSS_EXP_NOSTORE      // timing-only ablation: the tile is not written
+    if (active && t1[0][0][0] == 1.2345e-300)
+#else
+    if (active)
+#endif
+        corr_store<TS, M3, MASK>(tl, f, n, c, D, t1, t2, t3, R, P);
+}
+
+template <bool M3, int NW>
+__global__ __launch_bounds__(64 * NW) void wpe_corr_persist_kernel(
+    const cplx *__restrict__ Y, const double *__restrict__ w, int F, int64_t T, int D, int n,
+    int c, int pieces, const CorrTile *__restrict__ tiles, int ntiles, CorrQueue cq,
+    int *__restrict__ counters, cplx *__restrict__ R, cplx *__restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx *S0 = reinterpret_cast<cplx *>(smem);                       // 2 x pieces * 64
+    double *w0 = reinterpret_cast<double *>(S0 + 2 * pieces * 64);   // 2 x CORR_KT
+    __shared__ int ring[3];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int win = pieces * 64;
+    // HW_REG_XCC_ID (20), bits 3:0: the XCD this workgroup runs on
+    const int xcd = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;
+#ifdef GSS_CORR_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        g_corr_trace[blockIdx.x * 6 + 0] = xcd;
+        g_corr_trace[blockIdx.x * 6 + 1] = wall_clock64();
+        g_corr_trace[blockIdx.x * 6 + 2] = clock64();
+    }
+#endif
+    int live = 0;
+    if (threadIdx.x == 0) {
+        ring[0] = corr_fetch(counters, F, xcd, live, cq);
+        ring[1] = ring[0] < 0 ? -1 : corr_fetch(counters, F, xcd, live, cq);
+        ring[2] = -1;
+    }
+    __syncthreads();
+
+    // One window.  Inside the slab (all but the first and the last chunk of an item) a piece
+    // costs NO vector instruction: the lane part of the address (16 * lane) is one VGPR for
+    // the whole kernel, everything else -- slab offset of the piece, LDS destination -- is
+    // scalar (soffset, M0).  That matters here because a wave's VALU instruction can only
+    // issue between the 64-cycle f64 MFMAs of the other wave on its SIMD: 45 address / compare /
+    // select instructions per window kept wave 0 in this routine for 21 % of its life
+    // (tools/corr_trace_persist.py).  At the edges of the slab the elements before the first
+    // frame are lanes that store a zero instead, the elements past the last frame read as
+    // zeros through the raw buffer resource sized to the slab.
+    const uint32_t lane16 = lane * 16;
+    auto issue = [&](int fq, int64_t t0, int bq) {
+        const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<cplx *>(Y + (int64_t)fq * T * D), 0, (int)(T * D * 16), 0x00020000);
+        cplx *Sb = S0 + bq * win;
+        const int64_t g0 = (t0 - c) * (int64_t)D;
+        if (g0 >= 0 && g0 + win <= T * (int64_t)D) {
+            for (int p = wave; p < pieces; p += NW)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_void_ptr)(Sb + p * 64), 16,
+                                                         lane16, (int)((g0 + p * 64) * 16), 0, 0);
+        } else {
+            for (int p = wave; p < pieces; p += NW) {
+                const int64_t gp = g0 + p * 64;            // wave-uniform
+                const uint32_t voff = (uint32_t)((gp + lane) * 16);
+                if (gp >= 0) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_void_ptr)(Sb + p * 64),
+                                                             16, voff, 0, 0, 0);
+                } else if (gp + lane < 0) {
+                    Sb[p * 64 + lane] = c_make(0.0, 0.0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_void_ptr)(Sb + p * 64),
+                                                             16, voff, 0, 0, 0);
+                }
+            }
+        }
+        if (wave == NW - 1 && lane < CORR_KT / 2) {
+            // (weights past the last frame meet window elements that are zero)
+            const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<double *>(w + (int64_t)fq * T), 0, (int)(T * 8), 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void_ptr)(w0 + bq * CORR_KT), 16,
+                                                     lane16, (int)(t0 * 8), 0, 0);
+        }
+    };
+
+    int item = __builtin_amdgcn_readfirstlane(ring[0]);
+    if (item < 0) return;
+    int b = 0;
+    issue(item >> 12, 0, 0);
+    __syncthreads();
+    for (int k = 0; item >= 0; ++k) {
+        const int next = __builtin_amdgcn_readfirstlane(ring[(k + 1) % 3]);
+        int fetched = -1;
+        if (threadIdx.x == 0 && next >= 0) fetched = corr_fetch(counters, F, xcd, live, cq);
+        const int f = item >> 12, grp = item & 4095;
+        const int tile_id = grp * NW + wave;
+        const bool active = tile_id < ntiles;
+        const CorrTile tl = tiles[active ? tile_id : 0];
+        const int mask = __builtin_amdgcn_readfirstlane(active ? tl.mask : 1);
+        // (ring[(k + 2) % 3] was the slot of item k - 1: nobody reads it any more)
+        int *ring_slot = &ring[(k + 2) % 3];
+#define CORR_CASE(M)                                                                              \
+    case M:                                                                                       \
+        corr_item_dma<M3, M, NW>(T, D, n, c, win, S0, w0, tl, active, f, next < 0 ? -1 : next >> 12, \
+                                 b, issue, ring_slot, fetched, R, P);                             \
+        break
+        switch (mask) {
+            CORR_CASE(1);
+            CORR_CASE(3);
+            CORR_CASE(5);
+            CORR_CASE(11);
+            default:
+                corr_item_dma<M3, 15, NW>(T, D, n, c, win, S0, w0, tl, active, f,
+                                          next < 0 ? -1 : next >> 12, b, issue, ring_slot, fetched,
+                                          R, P);
+        }
+#undef CORR_CASE
+        item = next;
+#ifdef GSS_CORR_TRACE
+        if (threadIdx.x == 0 && blockIdx.x < 8192) {
+            g_corr_trace[blockIdx.x * 6 + 3] = wall_clock64();
+            g_corr_trace[blockIdx.x * 6 + 4] = clock64();
+            g_corr_trace[blockIdx.x * 6 + 5] = k + 1;
+        }
+#endif
+    }
 }
 
 // ------------------------------------------------------------------ solve
@@ -1423,7 +1789,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         ctx->wpe_tiles_key[2] != D || ctx->wpe_tiles_key[3] != corr_ts + (fold_diag ? 0 : 16)) {
         GSS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (!ctx->wpe_tiles)
-            GSS_HIP_CHECK(ctx, hipMalloc(&ctx->wpe_tiles, sizeof(CorrTile) * (1024 + 4096 + 1)));
+            GSS_HIP_CHECK(ctx, hipMalloc(&ctx->wpe_tiles, sizeof(CorrTile) * (1024 + 4096 + 1 + 64)));
         GSS_HIP_CHECK(ctx, hipMemcpy(ctx->wpe_tiles, tiles.data(), sizeof(CorrTile) * ntiles,
                                      hipMemcpyHostToDevice));
         if (!upd.empty())
@@ -1441,6 +1807,8 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     // copied to the context's status words at the end (gss_last_wpe_zero_pivots)
     int32_t *zero_pivots = reinterpret_cast<int32_t *>(tiles_dev + 1024 + 4096);
     GSS_HIP_CHECK(ctx, hipMemsetAsync(zero_pivots, 0, sizeof(int32_t), ctx->stream));
+    // work-queue heads of the persistent correlation kernel: 8 counters, 64 bytes apart
+    int *corr_counters = reinterpret_cast<int *>(tiles_dev + 1024 + 4096 + 1);
 
     const int padf = corr_padf(D, 16 * corr_ts);
     // 3 real MFMAs per complex product (t1 = ar br, t2 = ai bi, t3 = (ar + ai)(br - bi));
@@ -1546,6 +1914,43 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(corr_fn),
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)corr_lds));
+    // 32 x 32 tiles: the window by LDS-DMA into two alternating LDS windows (GSS_CORR_DMA=0:
+    // the register-staged kernel); needs the slab's byte offsets in 31 bits
+    const int corr_pieces = (int)(((size_t)(CORR_KT + c + padf) * D + 63) / 64);
+    const size_t corr_dma_lds = 2 * (sizeof(cplx) * 64 * (size_t)corr_pieces + sizeof(double) * CORR_KT);
+    const bool corr_dma = corr_ts == 2 && corr_3m && (int64_t)T * D * 16 < (1LL << 31) &&
+                          corr_dma_lds <= 80 * 1024 &&
+                          !(getenv("GSS_CORR_DMA") && atoi(getenv("GSS_CORR_DMA")) == 0);
+    // (two windows of one workgroup take half a CU's LDS at most, so that two workgroups share
+    // a CU; resident workgroups do not care how the item count packs into rounds: 4 waves)
+    if (corr_dma && !getenv("GSS_CORR_NW")) corr_nw = 4;
+    auto corr_dma_fn = corr_nw == 2 ? wpe_corr_dma_kernel<true, 2> : wpe_corr_dma_kernel<true, 4>;
+    if (corr_dma && corr_dma_lds > 64 * 1024)
+        GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(corr_dma_fn),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)corr_dma_lds));
+    // ... as resident workgroups fed from per-XCD item queues (GSS_CORR_PERSIST=0: one
+    // workgroup per item)
+    const bool corr_persist = corr_dma && !(getenv("GSS_CORR_PERSIST") && atoi(getenv("GSS_CORR_PERSIST")) == 0);
+    auto corr_persist_fn = corr_nw == 2 ? wpe_corr_persist_kernel<true, 2> : wpe_corr_persist_kernel<true, 4>;
+    CorrQueue corr_queue{(ntiles + corr_nw - 1) / corr_nw, 0};
+    int corr_slots = 0;
+    if (corr_persist) {
+        // heavy groups: the heaviest wave needs 3 or 4 of its tile's 4 sub-tiles
+        for (int g = 0; g < corr_queue.ngroups; ++g)
+            if (__builtin_popcount(tiles[g * corr_nw].mask) >= 3) corr_queue.gh = g + 1;
+        if (corr_dma_lds > 64 * 1024)
+            GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(corr_persist_fn),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)corr_dma_lds));
+        int per_cu = 0, cus = 0;
+        GSS_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                               &per_cu, reinterpret_cast<const void *>(corr_persist_fn), 64 * corr_nw,
+                               corr_dma_lds));
+        GSS_HIP_CHECK(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        if (const char *e = getenv("GSS_CORR_SLOTS_PER_CU")) per_cu = std::min(per_cu, atoi(e));
+        corr_slots = std::min(std::max(per_cu, 1) * cus, corr_queue.ngroups * F);
+    }
 
     for (int it = 0; it < iterations; ++it) {
         const cplx *cur = it == 0 ? Y : X;
@@ -1553,7 +1958,20 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
             GSS_PROF(ctx, "wpe_power");
             GSS_TRY(wpe_power_launch(ctx, cur, F, T, D, psd_context, raw, w));
         }
-        {
+        if (corr_persist) {
+            GSS_HIP_CHECK(ctx, hipMemsetAsync(corr_counters, 0, 8 * 16 * sizeof(int), ctx->stream));
+            GSS_PROF(ctx, "wpe_corr");
+            hipLaunchKernelGGL(corr_persist_fn, dim3(corr_slots), dim3(64 * corr_nw), corr_dma_lds,
+                               ctx->stream, Y, w, F, T, D, n, c, corr_pieces, tiles_dev, ntiles,
+                               corr_queue, corr_counters, R, P);
+            GSS_LAUNCH_CHECK(ctx, "wpe_corr_persist_kernel");
+        } else if (corr_dma) {
+            GSS_PROF(ctx, "wpe_corr");
+            hipLaunchKernelGGL(corr_dma_fn, dim3(xcd_grid((ntiles + corr_nw - 1) / corr_nw, F)),
+                               dim3(64 * corr_nw), corr_dma_lds, ctx->stream, Y, w, F, T, D, n, c,
+                               corr_pieces, tiles_dev, ntiles, R, P);
+            GSS_LAUNCH_CHECK(ctx, "wpe_corr_dma_kernel");
+        } else {
             GSS_PROF(ctx, "wpe_corr");
             hipLaunchKernelGGL(corr_fn, dim3(xcd_grid((ntiles + corr_nw - 1) / corr_nw, F)),
                                dim3(64 * corr_nw), corr_lds,
