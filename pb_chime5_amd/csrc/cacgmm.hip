@@ -909,6 +909,347 @@ __global__ __launch_bounds__(64) void em_eigh_kernel(const cplx *__restrict__ Bp
                       Mq + (int64_t)f * NE * K + k, logdet + f * K + k, ts);
 }
 
+// ------------------------------------------------------------------ one array: the whole EM in one launch
+// With one array (D = 4: the reference's default multiarray=False, BASELINE config 1) an EM
+// iteration is 71 MB of traffic and a few hundred thousand FMAs -- microseconds of work -- but
+// cost three dependent launches of ~25-40 us each (E-step, M-step, model update): ramp-up, two
+// memory round trips and a tail per launch, 60 of them per utterance.  Frequencies are
+// independent and a frequency's model is 50 complex numbers, so here ONE workgroup owns a
+// frequency for all iterations and nothing but the posteriors of the final predict step ever
+// leaves the chip: the model lives in LDS, the unit-normalised observation (139 KB per
+// frequency at T = 2169, L2 resident) is streamed once per iteration.  Per 256-frame chunk:
+//   phase E  lane = frame: quadratic forms against the model in LDS (broadcast reads), softmax
+//            -- the arithmetic of em_estep_reg_kernel --, the M-step weights w_kt and the 16
+//            real numbers of the frame's Hermitian products P_de into LDS (the (F, K, T) weight
+//            tensor does not exist);
+//   phase M  thread = (entry i, frame slice s): 16 entries x 16 slices, K accumulators each that
+//            run over ALL chunks of the iteration; w and P are read back from LDS.
+// After the last chunk a 16-lane DPP row sum finishes the K x 16 sums (no partial buffers,
+// no tickets, no fences: one workgroup saw every frame), wave w updates classes w, w + 4
+// (Cholesky + no-floor certificate, Jacobi eigh when flagged -- the code of em_chol / em_eigh)
+// and the next iteration starts.  20 iterations + predict = 1 launch instead of 61.
+__device__ __forceinline__ double row16_sum(double v) {      // total in lane 15 of each row
+    double s = v + dpp_shifted<0x111, 0xf, 0xf>(v);      // row_shr:1
+    s += dpp_shifted<0x112, 0xf, 0xf>(v);                // row_shr:2
+    s += dpp_shifted<0x113, 0xf, 0xf>(v);                // row_shr:3
+    s += dpp_shifted<0x114, 0xf, 0xe>(s);                // row_shr:4, banks 1-3
+    s += dpp_shifted<0x118, 0xf, 0xc>(s);                // row_shr:8, banks 2-3
+    return s;
+}
+
+constexpr int OC_FRAMES = 256;
+
+#ifdef GSS_EM4_TRACE
+// tools/em4_trace.py: shader cycles wave 0 of every workgroup spends per phase
+__device__ long long g_em4_phase[1024 * 6];
+extern "C" int gss_debug_em4_phase(long long *host, int entries) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_em4_phase), sizeof(long long) * 6 * entries);
+}
+#define EM4_T(var) const long long var = clock64()
+#define EM4_ADD(slot, d) if (tid == 0 && blockIdx.x < 1024) g_em4_phase[blockIdx.x * 6 + (slot)] += (d)
+#else
+#define EM4_T(var)
+#define EM4_ADD(slot, d)
+#endif
+
+struct OnchipArgs {
+    cplx *Mq;               // (F, NE, K) model scratch (written and re-read by the same workgroup)
+    const cplx *Yn;         // (F, 4, T) unit-normalised observation
+    const uint8_t *act;     // (K, act_stride)
+    int64_t act_stride, T;
+    int F, iterations, iterations_post, force_eigh;
+    double eig_floor;
+    double *gamma;          // (F, K, T)
+};
+
+template <int K>
+__global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
+    constexpr int D = 4, NE = 10, NP = 16;           // NP: real numbers per frame's products
+    // (rows padded by 128 bytes: the four entry rows a wave reads in phase M start in
+    // different halves of the 64 banks)
+    __shared__ __attribute__((aligned(16))) double wS[K][OC_FRAMES];
+    __shared__ __attribute__((aligned(16))) double pS[NP][OC_FRAMES + 16];
+    __shared__ double logdetS[K], piS[K], cS[K], sgS[4][K], bS[K][NP];
+    constexpr int CH_LD = 9;
+    __shared__ __attribute__((aligned(16))) char scratch[4][(2 * 4 * 4 + D * CH_LD) * sizeof(cplx) + 64];
+    const int64_t T = a.T;
+    const int f = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const cplx *yf = a.Yn + (int64_t)f * D * T;
+    // B_k^-1 (off-diagonals doubled) of this frequency: written to global memory by the class
+    // updates (vector stores, acknowledged by L2) and read back in phase E through the scalar
+    // data cache -- model rows as SGPR operands of the FMAs, like em_estep_reg_kernel; reading
+    // them from LDS instead was one exposed LDS round trip per triangle entry.  The scalar
+    // cache is invalidated after every update, and the pointer is laundered per iteration so
+    // that the compiler neither hoists the loads out of the iteration loop nor makes them
+    // vector loads.
+    cplx *Mq_rw = a.Mq + (int64_t)f * NE * K;
+    typedef const double __attribute__((address_space(4))) *const_model_ptr;   // (re, im) pairs
+    const int nsub = (int)((T + OC_FRAMES - 1) / OC_FRAMES);
+    const int mi = tid >> 4, msl = tid & 15;          // phase M: entry number, frame slice
+    const TriSlots ts = tri_slots(D, lane);
+
+    EM4_T(c_start);
+    // fit(I iterations, masked) + fit(post - 1 iterations, unmasked) + predict
+    const int n_fit = a.iterations + (a.iterations_post > 1 ? a.iterations_post - 1 : 0);
+    for (int it = 0; it <= n_fit; ++it) {
+        const bool first = it == 0 && a.iterations > 0;
+        const bool predict = it == n_fit;
+        const bool masked = predict ? a.iterations_post == 0 : it < a.iterations;
+        const double aff_eps = predict ? 0.0 : 1e-10;
+        double acc[K], sg[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = sg[k] = 0.0;
+        unsigned long long mq_bits = (unsigned long long)Mq_rw;
+        asm volatile("" : "+s"(mq_bits));
+        const_model_ptr Mc = (const_model_ptr)mq_bits;
+
+        // the frame of chunk sub + 1 is requested before chunk sub is evaluated
+        cplx yn[D];
+        uint8_t an[K];
+        auto fetch = [&](int sub) {
+            const int64_t t = (int64_t)sub * OC_FRAMES + tid;
+            const int64_t tc = t < T ? t : T - 1;
+#pragma unroll
+            for (int d = 0; d < D; ++d) yn[d] = yf[(int64_t)d * T + tc];
+#pragma unroll
+            for (int k = 0; k < K; ++k) an[k] = a.act[(int64_t)k * a.act_stride + tc];
+        };
+        fetch(0);
+        for (int sub = 0; sub < nsub; ++sub) {
+            EM4_T(c_a);
+            const int64_t t = (int64_t)sub * OC_FRAMES + tid;
+            const bool valid = t < T;
+            // ---- phase E
+            cplx y[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) y[d] = yn[d];
+            bool on[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) on[k] = valid && an[k] != 0;
+            if (sub + 1 < nsub) fetch(sub + 1);
+            // products of the frame: slots 0-3 |y_d|^2, then re and im of the 6 upper entries
+            double pv[NP];
+            {
+                int off = 0;
+#pragma unroll
+                for (int d1 = 0; d1 < D; ++d1)
+#pragma unroll
+                    for (int d2 = d1; d2 < D; ++d2) {
+                        const double pr = y[d1].x * y[d2].x + y[d1].y * y[d2].y;
+                        if (d1 == d2) {
+                            pv[d1] = pr;
+                        } else {
+                            pv[D + off] = pr;
+                            pv[D + 6 + off] = y[d1].y * y[d2].x - y[d1].x * y[d2].y;
+                            ++off;
+                        }
+                    }
+            }
+            double q[K], gam[K];
+            if (first) {
+                // GSS initialisation (core.py:156-160): where(act == 0, 1e-10, act) / sum_k; q = 1
+                double ssum = 0.0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    q[k] = 1.0;
+                    gam[k] = on[k] ? 1.0 : 1e-10;
+                    ssum += gam[k];
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) gam[k] /= ssum;
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) q[k] = 0.0;
+                int e = 0, off = 0;
+#pragma unroll
+                for (int d1 = 0; d1 < D; ++d1)
+#pragma unroll
+                    for (int d2 = d1; d2 < D; ++d2, ++e) {
+                        const double pr = d1 == d2 ? pv[d1] : pv[D + off];
+                        const double pim = d1 == d2 ? 0.0 : pv[D + 6 + off];
+                        if (d1 != d2) ++off;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            q[k] = fma(Mc[2 * (e * K + k)], pr, q[k]);
+                            q[k] = fma(Mc[2 * (e * K + k) + 1], pim, q[k]);
+                        }
+                    }
+                double ssum = 0.0;
+#ifndef GSS_EM4_LOG_SOFTMAX
+                // pi_k exp(-D ln q_k - ln det_k - max) with D = 4 and no logarithm: relative to
+                // the class with the smallest q it is  (q_min / q_k)^4 * cS[k]  with
+                // cS[k] = pi_k exp(ln det_min - ln det_k)  from the model update -- K
+                // exponentials per iteration instead of 2 K transcendental functions per frame
+                // (450 of the 765 VALU instructions of phase E; -27 % on the kernel).  The
+                // common factor between the two forms cancels in the normalisation; it is
+                // bounded below by (1e-10)^(2 D) = 1e-80 -- eigenvalue floor / no-floor
+                // certificate --, so nothing underflows that the log form keeps.
+                // -DGSS_EM4_LOG_SOFTMAX builds the log / exp form of em_estep_reg_kernel.
+                double qmin = INFINITY;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    q[k] = fmax(fabs(q[k]), GSS_TINY);
+                    qmin = fmin(qmin, q[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const double r = qmin / q[k], r2 = r * r;
+                    gam[k] = (r2 * r2) * cS[k];
+                    if (masked) gam[k] *= on[k] ? 1.0 : 0.0;
+                    ssum += gam[k];
+                }
+#else
+                double lp[K], mx = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    q[k] = fmax(fabs(q[k]), GSS_TINY);
+                    lp[k] = -(double)D * log(q[k]) - logdetS[k];
+                    mx = fmax(mx, lp[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    gam[k] = exp(lp[k] - mx) * piS[k];
+                    if (masked) gam[k] *= on[k] ? 1.0 : 0.0;
+                    ssum += gam[k];
+                }
+#endif
+                ssum = fmax(ssum, GSS_TINY);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    gam[k] = gam[k] / ssum;
+                    if (aff_eps != 0.0) gam[k] = fmin(fmax(gam[k], aff_eps), 1.0 - aff_eps);
+                }
+            }
+            if (predict) {
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    if (valid) a.gamma[((int64_t)f * K + k) * T + t] = gam[k];
+                continue;
+            }
+            EM4_T(c_b);
+            __syncthreads();                  // phase M of the previous chunk is done with LDS
+            EM4_T(c_c);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double wk = first ? gam[k] : gam[k] / fmax(q[k], 10.0 * GSS_TINY);
+                wS[k][tid] = valid ? wk : 0.0;
+                sg[k] += valid ? gam[k] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < NP; ++i) pS[i][tid] = pv[i];
+            __syncthreads();
+            EM4_T(c_d);
+            // ---- phase M: thread (entry i, slice s) adds w_kt P_i(t) for the frame pairs
+            // t = 2 s + 32 j (16-byte LDS reads: one of P, K of w per 2 K FMAs)
+            // (operands of step j + 1 are requested before the FMAs of step j)
+            double2 pb[2], wb[2][K];
+            auto mload = [&](int j, int slot) {
+                const int tt = 2 * msl + 32 * j;
+                pb[slot] = *reinterpret_cast<const double2 *>(&pS[mi][tt]);
+#pragma unroll
+                for (int k = 0; k < K; ++k) wb[slot][k] = *reinterpret_cast<const double2 *>(&wS[k][tt]);
+            };
+            mload(0, 0);
+#pragma unroll
+            for (int j = 0; j < OC_FRAMES / 32; ++j) {
+                if (j + 1 < OC_FRAMES / 32) mload(j + 1, (j + 1) & 1);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    acc[k] = fma(wb[j & 1][k].x, pb[j & 1].x, acc[k]);
+                    acc[k] = fma(wb[j & 1][k].y, pb[j & 1].y, acc[k]);
+                }
+            }
+#ifdef GSS_EM4_TRACE
+            {
+                EM4_T(c_e);
+                EM4_ADD(0, c_b - c_a);     // phase E
+                EM4_ADD(1, c_c - c_b);     // barrier 1
+                EM4_ADD(2, c_d - c_c);     // LDS stores + barrier 2
+                EM4_ADD(3, c_e - c_d);     // phase M
+            }
+#endif
+        }
+        if (predict) break;
+        EM4_T(c_f);
+
+        // ---- the iteration's sums: B_k entries (K x 16 real numbers) and sum_t gamma_kt
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double tot = row16_sum(acc[k]);
+            if (msl == 15) bS[k][mi] = tot;
+            const double g = wave_sum(sg[k]);
+            if (lane == 0) sgS[wave][k] = g;
+        }
+        __syncthreads();
+        // ---- model update: wave w takes classes w, w + 4 (one wave per class matrix, as em_chol)
+        for (int k = wave; k < K; k += 4) {
+            const double sgk = (sgS[0][k] + sgS[1][k]) + (sgS[2][k] + sgS[3][k]);
+            const double den = fmax(sgk, GSS_TINY);
+            if (lane == 0) piS[k] = sgk / (double)T;
+            // packed upper triangle (row major): diagonals are entries 0, 4, 7, 9 (slots 0-3 of
+            // bS), the six others in walk order (re: slots 4-9, im: slots 10-15)
+            cplx vals[COV_SLOTS];
+#pragma unroll
+            for (int s2 = 0; s2 < COV_SLOTS; ++s2) vals[s2] = c_make(0.0, 0.0);
+            double tr = 0.0;
+            if (lane < NE) {
+                const int p = ts.d12[0], d1 = p >> 8, d2 = p & 255;
+                if (d1 == d2) {
+                    vals[0] = c_make(((double)D * bS[k][d1]) / den, 0.0);
+                    tr = vals[0].x;
+                } else {
+                    const int off = lane - d1 - 1;          // entries before it minus diagonals
+                    vals[0] = c_make(((double)D * bS[k][D + off]) / den,
+                                     ((double)D * bS[k][D + 6 + off]) / den);
+                }
+            }
+            tr = wave_sum(tr);
+            cplx *A = reinterpret_cast<cplx *>(scratch[wave]);
+            bool fast = !a.force_eigh && tr > 0.0 && isfinite(tr);
+            if (fast)
+                fast = class_update_chol<1>(vals, D, K, a.eig_floor, A, lane, Mq_rw + k, logdetS + k, ts);
+            if (!fast) {
+                wave_sync();
+                class_update_eigh(vals, D, K, a.eig_floor, A, lane, Mq_rw + k, logdetS + k, ts);
+            }
+            wave_sync();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the model stores are in L2
+        __syncthreads();
+        __builtin_amdgcn_s_dcache_inv();
+#ifdef GSS_EM4_TRACE
+        {
+            EM4_T(c_g);
+            EM4_ADD(4, c_g - c_f);         // sums + model update
+        }
+#endif
+#ifndef GSS_EM4_LOG_SOFTMAX
+        if (tid < K) {
+            double ldmin = INFINITY;
+            for (int k = 0; k < K; ++k) ldmin = fmin(ldmin, logdetS[k]);
+            cS[tid] = piS[tid] * exp(ldmin - logdetS[tid]);
+        }
+        __syncthreads();
+#endif
+    }
+#ifdef GSS_EM4_TRACE
+    {
+        EM4_T(c_end);
+        EM4_ADD(5, c_end - c_start);
+    }
+#endif
+}
+
+template <int K>
+int launch_onchip4(gss_ctx *ctx, const OnchipArgs &a) {
+    GSS_PROF(ctx, "em_onchip");
+    hipLaunchKernelGGL(em_onchip4_kernel<K>, dim3(a.F), dim3(256), 0, ctx->stream, a);
+    GSS_LAUNCH_CHECK(ctx, "em_onchip4_kernel");
+    return GSS_OK;
+}
+
 size_t em_estep_lds(int D, int K) {
     size_t b = sizeof(cplx) * (size_t)D * EM_TS;
     b += sizeof(double) * ((size_t)4 * K * EM_TILE + 2 * (size_t)K * EM_TILE + 2 * K);
@@ -1207,6 +1548,29 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
         }
         return GSS_OK;
     };
+
+    // one array: the whole EM (all iterations + predict) in one launch (em_onchip4_kernel)
+    if (D == 4 && K >= 2 && K <= 6 && reg && iterations > 0 && getenv("GSS_EM_UNFUSED") == nullptr) {
+        OnchipArgs o{};
+        o.Mq = Mq;
+        o.Yn = Yn;
+        o.act = act;
+        o.act_stride = act_stride;
+        o.T = T;
+        o.F = F;
+        o.iterations = iterations;
+        o.iterations_post = iterations_post;
+        o.force_eigh = force_eigh;
+        o.eig_floor = 1e-10;
+        o.gamma = gamma;
+        switch (K) {
+            case 2: return launch_onchip4<2>(ctx, o);
+            case 3: return launch_onchip4<3>(ctx, o);
+            case 4: return launch_onchip4<4>(ctx, o);
+            case 5: return launch_onchip4<5>(ctx, o);
+            default: return launch_onchip4<6>(ctx, o);
+        }
+    }
 
     // CACGMMTrainer.fit(initialization=array, iterations=I, source_activity_mask)
     auto em_iteration = [&](bool first) -> int {

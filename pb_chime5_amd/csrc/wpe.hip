@@ -274,11 +274,15 @@ __device__ __forceinline__ void corr_store(const CorrTile &tl, int f, int n, int
                                            (t3[a][b][reg] - t1[a][b][reg]) + t2[a][b][reg])
                                   : c_make(t1[a][b][reg], t3[a][b][reg]);
                 if (r >= n) continue;
-                if (tl.is_p) {
+                if (tl.is_p == 1) {
                     const int d = cc - c * D;
                     if (d >= 0 && d < D) Pf[r * D + d] = v;
-                } else if (cc < n) {
-                    Rf[r * n + cc] = v;
+                } else {
+                    if (cc < n) Rf[r * n + cc] = v;
+                    if (tl.is_p == 2) {          // a tile of R's last column that also holds P
+                        const int d = cc - c * D;      // (P overlaps R's own columns when c D < n)
+                        if (d >= 0 && d < D) Pf[r * D + d] = v;
+                    }
                 }
             }
 }
@@ -1668,12 +1672,26 @@ static int corr_tiles(int n, int D, int c, int ct, std::vector<CorrTile> &tiles)
             }
         return m;
     };
+    // P = Gram columns [c D, c D + D).  When they all fall into the LAST column tile of R
+    // (one array at 10 taps, delay 2: n = 40 is padded to 48 and P sits at 44..47), every row
+    // block's tile of that column already computes them -- the tile is marked 2 ("R and P") and
+    // no P tile is launched: 6 waves per frequency instead of 9.
+    const int last_col = (n - 1) / ct;
+    // (16 x 16 tiles only: a diagonal 32 x 32 tile skips its sub-tile below the diagonal)
+    const bool p_folded = ct == 16 && (c * D) / ct == last_col && (c * D + D - 1) / ct == last_col &&
+                          getenv("GSS_CORR_P_TILES") == nullptr;
     for (int r0 = 0; r0 < n; r0 += ct)
         for (int c0 = 0; c0 < n; c0 += ct)
-            if (c0 + ct > r0) tiles.push_back({r0, c0, 0, mask_of(r0, c0, n, true)});
-    for (int r0 = 0; r0 < n; r0 += ct)
-        for (int c0 = 0; c0 < D; c0 += ct)
-            tiles.push_back({r0, c * D + c0, 1, mask_of(r0, c0, D, false)});
+            if (c0 + ct > r0) {
+                const bool with_p = p_folded && c0 / ct == last_col;
+                // (the sub-tiles that hold P columns are needed even where R ends before them)
+                tiles.push_back({r0, c0, with_p ? 2 : 0,
+                                 mask_of(r0, c0, with_p ? std::max(n, c * D + D) : n, true)});
+            }
+    if (!p_folded)
+        for (int r0 = 0; r0 < n; r0 += ct)
+            for (int c0 = 0; c0 < D; c0 += ct)
+                tiles.push_back({r0, c * D + c0, 1, mask_of(r0, c0, D, false)});
     // heaviest first, so that the four waves of a workgroup carry similar loads
     std::stable_sort(tiles.begin(), tiles.end(), [](const CorrTile &x, const CorrTile &y) {
         return __builtin_popcount(x.mask) > __builtin_popcount(y.mask);
