@@ -466,12 +466,32 @@ def profile_kernels(ctx, res, utt, steps):
 
 def em_loop_entry(prof, steps, iterations, F, T, D, K, roofline):
     """EM loop (E-step, M-step, model update) per iteration against both roofs
-    (bytes = one pass over the STFT tensor, B_Y = 16 F T D in c128)."""
+    (bytes = one pass over the STFT tensor, B_Y = 16 F T D in c128).  One array
+    (D = 4): the whole loop is ONE launch (em_onchip: 20 iterations + predict, the observation
+    streamed once per pass and nothing else -- no weight tensor, no partial sums)."""
+    size = dict(F=F, T=T, D=D, K=K, taps=1, N=0)
+    by = roofline.stft_bin_bytes(F, T, D)
+    flops = sum(roofline.kernel_work(n, **size)['flops'] for n in ('em_estep', 'em_mstep', 'em_chol'))
+    if 'em_onchip' in prof:
+        passes = iterations + 1                      # + the predict pass, same traffic, E only
+        ms_pass = prof['em_onchip']['ms'] / steps / passes
+        sec = ms_pass * 1e-3
+        return {
+            'kernel': 'em_onchip (one launch per utterance: all iterations + predict)',
+            'channels': D, 'frames': T, 'classes': K, 'launches_per_utterance': 1,
+            'ms_per_utterance': prof['em_onchip']['ms'] / steps,
+            'ms_per_iteration': ms_pass, 'passes': passes,
+            'algorithmic_bytes_per_iteration': by,
+            'bytes_note': 'ONE pass over the unit-normalised observation per iteration; the '
+                          'model, the M-step weights and all sums stay on chip',
+            'hbm_frac': by / sec / 1e9 / roofline.PEAK_HBM_GBS,
+            'executed_flops_per_iteration': flops,
+            'valu_f64_frac': flops / sec / 1e12 / roofline.PEAK_F64_TFLOPS,
+            'binding_roof': 'latency / VALU issue at 2 workgroups per CU (513 frequencies on 256 '
+                            'CUs; tools/em4_trace.py)',
+        }
     names = [n for n in ('em_estep', 'em_mstep', 'em_chol', 'em_eigh') if n in prof]
     ms_iter = sum(prof[n]['ms'] for n in names) / steps / iterations
-    by = roofline.stft_bin_bytes(F, T, D)
-    size = dict(F=F, T=T, D=D, K=K, taps=1, N=0)
-    flops = sum(roofline.kernel_work(n, **size)['flops'] for n in ('em_estep', 'em_mstep', 'em_chol'))
     sec = ms_iter * 1e-3
     # the E-step alone against the roof that binds it: VALU issue (a wave64 f64 instruction
     # holds its SIMD for 4 cycles; tools/micro/valu_f64_bench.hip).  Priced at the NOMINAL
@@ -565,6 +585,7 @@ def main():
     torch.cuda.set_device(device_index)
     dist = None
     coll_device = 'cpu'
+    backend = None
     if world > 1:
         # RCCL when every rank has its own GPU (the contract's launch), gloo when ranks
         # share devices; either way it only carries barriers and two scalars.
@@ -779,6 +800,8 @@ def main():
                 'config': {'workload': block['workload'], 'sharding': block['sharding'],
                            'parallelism': f'utterance-sharded x{args.gpus}'
                                           + (' (ranks share GPUs)' if shared_devices else '')},
+                'ranks': world, 'rank_backend': backend if world > 1 else None,
+                'rccl_ranks': world if backend == 'nccl' else 0, 'collectives_on_data_path': 0,
                 'config4_standin': block,
             }
             emit(line)
@@ -801,6 +824,8 @@ def main():
                 'config': {'workload': block['workload'], 'sharding': block['sharding'],
                            'parallelism': f'utterance-sharded x{args.gpus}'
                                           + (' (ranks share GPUs)' if shared_devices else '')},
+                'ranks': world, 'rank_backend': backend if world > 1 else None,
+                'rccl_ranks': world if backend == 'nccl' else 0, 'collectives_on_data_path': 0,
                 'config3_sharded': block,
             }
             emit(line)
@@ -850,7 +875,9 @@ def main():
     ctx.profile_filter(None)
     x_hat = resident.result()
     assert np.all(np.isfinite(x_hat)) and x_hat.shape[0] == resident.n_out
+    elapsed_local = elapsed
     elapsed = max_over_ranks(elapsed)
+    headline_rows = gather_over_ranks([elapsed_local])
 
     extras = not args.only_headline
     # ---- session mode on the same workload: 2 in flight, H2D + D2H inside the wall clock
@@ -863,14 +890,18 @@ def main():
         run_session(pipe, range(args.inflight + 1), lambda i: item)
         barrier()
         t2 = time.perf_counter()
-        run_session(pipe, range(n2), lambda i: item)
-        e2 = time.perf_counter() - t2
+        clock2 = {}
+        run_session(pipe, range(n2), lambda i: item, clock2)
+        e2_local = time.perf_counter() - t2
         barrier()
-        e2 = max_over_ranks(e2)
+        e2 = max_over_ranks(e2_local)
+        rows2 = gather_over_ranks([e2_local, clock2['enqueue_s'], clock2['gpu_wait_s']])
         pipe.close()
         incl = {'value': args.gpus * n2 * utt.seconds / e2, 'unit': 'utterance-seconds/s',
                 'utterances_per_rank': n2, 'utterances_in_flight_per_gpu': args.inflight,
                 'ms_per_utterance': 1e3 * e2 / n2,
+                'per_rank': [dict(rank=r, wall_s=v[0], value=n2 * utt.seconds / v[0],
+                                  enqueue_s=v[1], gpu_wait_s=v[2]) for r, v in enumerate(rows2)],
                 'includes': 'H2D of the 24 x 240000 PCM16 samples + activity and D2H of the float64 '
                             'result for every utterance (pageable host memory)'}
 
@@ -975,6 +1006,16 @@ def main():
                                + (' (ranks share GPUs)' if shared_devices else ''),
             },
             'realtime_factor_per_gpu': steps * utt.seconds / elapsed,
+            # per rank (= per GPU when every rank has its own): the timed region of each rank
+            'per_rank': [dict(rank=r, ms_per_step=1e3 * v[0] / steps, value=steps * utt.seconds / v[0])
+                         for r, v in enumerate(headline_rows)],
+            'ranks': world, 'rank_backend': backend if world > 1 else None,
+            'rccl_ranks': world if backend == 'nccl' else 0,
+            'collectives_on_data_path': 0,
+            # what Enhancer.enhance_session does per GPU (two utterances in flight, PCM16 H2D +
+            # float64 D2H inside the wall clock): the figure to quote per GPU for a session
+            'value_session': incl['value'] if incl else None,
+            'value_session_per_gpu': incl['value'] / args.gpus if incl else None,
             'value_incl_pcie': incl['value'] if incl else None,
             'session_mode': incl,
             'roofline': roof,

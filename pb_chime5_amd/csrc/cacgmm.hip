@@ -960,7 +960,29 @@ struct OnchipArgs {
     int F, iterations, iterations_post, force_eigh;
     double eig_floor;
     double *gamma;          // (F, K, T)
+    // The last frequency split over coop_g workgroups (0: not split).  513 = 2 * 256 + 1
+    // frequencies on 256 CUs leave ONE CU with three workgroups, and the launch waits for it
+    // (slowest workgroup 1.3 x the fastest): workgroups F - 1 ... F - 2 + coop_g take every
+    // coop_g-th chunk of frequency F - 1 each, so that eight CUs carry 2 1/8 shares instead of
+    // one carrying 3.  Per iteration they hand their sums to the first of them and receive the
+    // model back through `coop` -- agent-scope atomics only (plain data is not coherent between
+    // the L2s of different XCDs inside a launch): [arrive, ready] counters, coop_g partial
+    // records, one model record.
+    int coop_g;
+    double *coop;
+    cplx *Mq_coop;          // (coop_g, NE, K): each helper's private copy of the model
 };
+
+__device__ __forceinline__ void coop_store(double *p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double coop_load(const double *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void coop_wait(int *flag, int value) {       // one thread
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value)
+        __builtin_amdgcn_s_sleep(16);
+}
 
 template <int K>
 __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
@@ -970,10 +992,19 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
     __shared__ __attribute__((aligned(16))) double wS[K][OC_FRAMES];
     __shared__ __attribute__((aligned(16))) double pS[NP][OC_FRAMES + 16];
     __shared__ double logdetS[K], piS[K], cS[K], sgS[4][K], bS[K][NP];
+    __shared__ __attribute__((aligned(16))) cplx MqS[NE * K];
     constexpr int CH_LD = 9;
     __shared__ __attribute__((aligned(16))) char scratch[4][(2 * 4 * 4 + D * CH_LD) * sizeof(cplx) + 64];
     const int64_t T = a.T;
-    const int f = blockIdx.x;
+    // the last frequency may be shared by coop_g workgroups (OnchipArgs): helper cg takes the
+    // chunks cg, cg + coop_g, ...
+    const bool coop = a.coop_g > 0 && (int)blockIdx.x >= a.F - 1;
+    const int cg = coop ? (int)blockIdx.x - (a.F - 1) : 0;
+    const int f = coop ? a.F - 1 : (int)blockIdx.x;
+    const int sub0 = coop ? cg : 0, sub_step = coop ? a.coop_g : 1;
+    constexpr int PART = K * NP + K;                   // one helper's sums per iteration
+    int *coop_flags = reinterpret_cast<int *>(a.coop);
+    double *coop_part = a.coop + 2, *coop_model = a.coop + 2 + (size_t)(coop ? a.coop_g : 0) * PART;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const cplx *yf = a.Yn + (int64_t)f * D * T;
@@ -984,7 +1015,7 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
     // cache is invalidated after every update, and the pointer is laundered per iteration so
     // that the compiler neither hoists the loads out of the iteration loop nor makes them
     // vector loads.
-    cplx *Mq_rw = a.Mq + (int64_t)f * NE * K;
+    cplx *Mq_rw = coop && cg > 0 ? a.Mq_coop + (int64_t)cg * NE * K : a.Mq + (int64_t)f * NE * K;
     typedef const double __attribute__((address_space(4))) *const_model_ptr;   // (re, im) pairs
     const int nsub = (int)((T + OC_FRAMES - 1) / OC_FRAMES);
     const int mi = tid >> 4, msl = tid & 15;          // phase M: entry number, frame slice
@@ -1016,8 +1047,8 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
 #pragma unroll
             for (int k = 0; k < K; ++k) an[k] = a.act[(int64_t)k * a.act_stride + tc];
         };
-        fetch(0);
-        for (int sub = 0; sub < nsub; ++sub) {
+        fetch(sub0);
+        for (int sub = sub0; sub < nsub; sub += sub_step) {
             EM4_T(c_a);
             const int64_t t = (int64_t)sub * OC_FRAMES + tid;
             const bool valid = t < T;
@@ -1028,7 +1059,7 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
             bool on[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) on[k] = valid && an[k] != 0;
-            if (sub + 1 < nsub) fetch(sub + 1);
+            if (sub + sub_step < nsub) fetch(sub + sub_step);
             // products of the frame: slots 0-3 |y_d|^2, then re and im of the 6 upper entries
             double pv[NP];
             {
@@ -1183,7 +1214,35 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
             if (lane == 0) sgS[wave][k] = g;
         }
         __syncthreads();
+        bool update = true;
+        if (coop) {
+            // every helper publishes its sums; helper 0 adds them up in helper order
+            if (tid < K * NP) coop_store(coop_part + (size_t)cg * PART + tid, bS[tid / NP][tid % NP]);
+            else if (tid < PART)
+                coop_store(coop_part + (size_t)cg * PART + tid,
+                           (sgS[0][tid - K * NP] + sgS[1][tid - K * NP]) +
+                               (sgS[2][tid - K * NP] + sgS[3][tid - K * NP]));
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_fetch_add(coop_flags, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            update = cg == 0;
+            if (update) {
+                if (tid == 0) coop_wait(coop_flags, a.coop_g * (it + 1));
+                __syncthreads();
+                if (tid < PART) {
+                    double tot = 0.0;
+                    for (int h = 0; h < a.coop_g; ++h) tot += coop_load(coop_part + (size_t)h * PART + tid);
+                    if (tid < K * NP) bS[tid / NP][tid % NP] = tot;
+                    else {
+                        sgS[0][tid - K * NP] = tot;
+                        sgS[1][tid - K * NP] = sgS[2][tid - K * NP] = sgS[3][tid - K * NP] = 0.0;
+                    }
+                }
+                __syncthreads();
+            }
+        }
         // ---- model update: wave w takes classes w, w + 4 (one wave per class matrix, as em_chol)
+        if (update)
         for (int k = wave; k < K; k += 4) {
             const double sgk = (sgS[0][k] + sgS[1][k]) + (sgS[2][k] + sgS[3][k]);
             const double den = fmax(sgk, GSS_TINY);
@@ -1209,13 +1268,36 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
             cplx *A = reinterpret_cast<cplx *>(scratch[wave]);
             bool fast = !a.force_eigh && tr > 0.0 && isfinite(tr);
             if (fast)
-                fast = class_update_chol<1>(vals, D, K, a.eig_floor, A, lane, Mq_rw + k, logdetS + k, ts);
+                fast = class_update_chol<1>(vals, D, K, a.eig_floor, A, lane, MqS + k, logdetS + k, ts);
             if (!fast) {
                 wave_sync();
-                class_update_eigh(vals, D, K, a.eig_floor, A, lane, Mq_rw + k, logdetS + k, ts);
+                class_update_eigh(vals, D, K, a.eig_floor, A, lane, MqS + k, logdetS + k, ts);
             }
             wave_sync();
         }
+        __syncthreads();
+        if (coop) {
+            // helper 0 hands the model on: B^-1 rows, ln det, pi; the others wait for it
+            double *mS = reinterpret_cast<double *>(MqS);
+            if (update) {
+                if (tid < 2 * NE * K) coop_store(coop_model + tid, mS[tid]);
+                else if (tid < 2 * NE * K + K) coop_store(coop_model + tid, logdetS[tid - 2 * NE * K]);
+                else if (tid < 2 * NE * K + 2 * K) coop_store(coop_model + tid, piS[tid - 2 * NE * K - K]);
+                __syncthreads();
+                if (tid == 0)
+                    __hip_atomic_store(coop_flags + 1, it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (tid == 0) coop_wait(coop_flags + 1, it + 1);
+                __syncthreads();
+                if (tid < 2 * NE * K) mS[tid] = coop_load(coop_model + tid);
+                else if (tid < 2 * NE * K + K) logdetS[tid - 2 * NE * K] = coop_load(coop_model + tid);
+                else if (tid < 2 * NE * K + 2 * K) piS[tid - 2 * NE * K - K] = coop_load(coop_model + tid);
+                __syncthreads();
+            }
+        }
+        // B^-1 to this workgroup's copy in global memory, where phase E reads it through the
+        // scalar cache
+        if (tid < NE * K) Mq_rw[tid] = MqS[tid];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the model stores are in L2
         __syncthreads();
         __builtin_amdgcn_s_dcache_inv();
@@ -1244,8 +1326,11 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
 
 template <int K>
 int launch_onchip4(gss_ctx *ctx, const OnchipArgs &a) {
+    if (a.coop_g > 0)      // arrive / ready counters of the shared frequency
+        GSS_HIP_CHECK(ctx, hipMemsetAsync(a.coop, 0, 16, ctx->stream));
     GSS_PROF(ctx, "em_onchip");
-    hipLaunchKernelGGL(em_onchip4_kernel<K>, dim3(a.F), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(em_onchip4_kernel<K>, dim3(a.F - (a.coop_g > 0 ? 1 : 0) + a.coop_g), dim3(256),
+                       0, ctx->stream, a);
     GSS_LAUNCH_CHECK(ctx, "em_onchip4_kernel");
     return GSS_OK;
 }
@@ -1458,6 +1543,7 @@ size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K) {
     b += align_up(sizeof(int) * (size_t)F * K);                  // need_eigh
     b += align_up(sizeof(cplx) * (size_t)F * D * T);             // Yn (register-form E-step)
     b += align_up(sizeof(double) * (size_t)F * ((T + 63) / 64 + 4) * K);
+    b += 2 * align_up(16 * (2 + 16 * (K * 17) + 2 * NE * K + 2 * K + 8 + 16 * NE * K));   // em_onchip coop
     return b + 4096;
 }
 
@@ -1563,6 +1649,18 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
         o.force_eigh = force_eigh;
         o.eig_floor = 1e-10;
         o.gamma = gamma;
+        // share the last frequency when the count is one more than the CUs can take in equal
+        // parts (513 on 256 CUs) and there are chunks to share (GSS_EM4_COOP=0: never)
+        const int nsub = (int)((T + OC_FRAMES - 1) / OC_FRAMES);
+        int coop_g = F > 256 && F % 256 == 1 && nsub >= 4 ? std::min(8, nsub) : 0;
+        if (const char *e = getenv("GSS_EM4_COOP")) coop_g = std::min(std::max(atoi(e), 0), std::min(nsub, 16));
+        if (coop_g == 1) coop_g = 0;
+        if (coop_g > 0) {
+            o.coop_g = coop_g;
+            o.coop = arena_alloc_t<double>(ctx, 2 + (size_t)coop_g * (K * 16 + K) + 2 * NE * K + 2 * K + 8);
+            o.Mq_coop = arena_alloc_t<cplx>(ctx, (size_t)coop_g * NE * K);
+            GSS_REQUIRE(ctx, o.coop && o.Mq_coop, GSS_ERR_NOMEM, "cacgmm workspace");
+        }
         switch (K) {
             case 2: return launch_onchip4<2>(ctx, o);
             case 3: return launch_onchip4<3>(ctx, o);

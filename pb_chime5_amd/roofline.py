@@ -13,6 +13,14 @@ figures of SURVEY.md section 8d (written for complex64) are doubled:
 # * 1024 SIMDs * 2.4 GHz = 78.6e12); the guide lists no f64 row.
 PEAK_HBM_GBS = 8000.0
 PEAK_F64_TFLOPS = 78.6
+# What v_mfma_f64_16x16x4_f64 sustains on this silicon, MEASURED (tools/micro/mfma_f64_bench.hip,
+# profiles/r04b_mfma_f64_bench.txt): 12 independent MFMAs per k-step alone issue every 65.0 cycles
+# per SIMD (77.6 TFLOP/s at the 2.40 GHz the kernel holds); with the instruction mix of the
+# wpe_corr k-step around them -- 8 f64 VALU operand products and 5 LDS operand reads per 12
+# MFMAs -- every 68.3 cycles (73.5 TFLOP/s): f64 VALU instructions run on the lanes the f64 MFMA
+# uses, so they are not hidden behind it however many waves share the SIMD.
+MEASURED_F64_MFMA_TFLOPS = 77.6
+MEASURED_WPE_CORR_MIX_TFLOPS = 73.5
 # Scalar data cache: what one CU can feed its waves through s_load_dwordx16, MEASURED
 # (tools/micro/smem_bench.hip, profiles/r03_smem_bench.txt: 16 waves per CU streaming 64-byte
 # lines that hit the cache, four requests per wait: 122.7 loads / us / CU = 3.27 bytes per cycle
@@ -65,6 +73,9 @@ def kernel_work(name, *, F, T, D, K, taps, N):
         need = n * (n + 1) // 2 + n * D
         sub = -(-n // 16)
         subtiles = sub * (sub + 1) // 2 + sub * -(-D // 16)
+        c = (n // D) + 1 if D else 0          # delay 2: c = taps + 1 frames back
+        if D <= 12 and (c * D) // 16 == (c * D + D - 1) // 16 == sub - 1:
+            subtiles = sub * (sub + 1) // 2   # P sits in R's last column tile (one array)
         return dict(flops=F * 6.0 * need * T, bytes=BY + 8.0 * F * T, bound='mfma',
                     dense_flops=F * (8.0 * n * n * T + 8.0 * n * D * T),
                     executed_flops=F * 6.0 * subtiles * 256 * T)
@@ -126,6 +137,14 @@ def roofline_entry(name, avg_ms, **size):
     if 'executed_flops' in w:
         out['frac_executed'] = w['executed_flops'] / sec / 1e12 / peak
         out['executed_flops_per_launch'] = w['executed_flops']
+        if name == 'wpe_corr':
+            out['frac_executed_of_measured_ceiling'] = (w['executed_flops'] / sec / 1e12
+                                                        / MEASURED_WPE_CORR_MIX_TFLOPS)
+            out['measured_ceiling_note'] = (
+                f'{MEASURED_WPE_CORR_MIX_TFLOPS} TFLOP/s: what back-to-back f64 MFMAs sustain with this '
+                'kernel\'s 8 f64 operand products + 5 LDS reads per 12 MFMAs around them '
+                f'({MEASURED_F64_MFMA_TFLOPS} alone); tools/micro/mfma_f64_bench.hip, '
+                'profiles/r04b_mfma_f64_bench.txt')
     if 'dense_flops' in w:
         out['note'] = ('frac prices the minimum real flops of the formulation (Hermitian upper '
                        'triangle, 3 real products per complex one) and is <= 1 by construction; '

@@ -155,11 +155,15 @@ def write_dev_shaped_session(root, session_id='S02', seconds=660.0, num_utteranc
     audio_dir = root / 'audio' / dataset
     audio_dir.mkdir(parents=True, exist_ok=True)
 
+    # utterances stay one context (15 s) + 1 s away from both ends of the recording when it is
+    # long enough: an utterance whose nominal context reaches past the recording has its whole
+    # target mask zeroed by bf_drop_context and ends in 0 / 0 -- in the reference too
+    margin = 16 * SAMPLE_RATE if n_total > 80 * SAMPLE_RATE else SAMPLE_RATE // 2
     utterances = []
     for i in range(num_utterances):
         spk = speakers[i % len(speakers)]
         length = min(config3_core_samples(seed * 100000 + i), n_total // 4)
-        start = int(rng.integers(SAMPLE_RATE // 2, n_total - length - SAMPLE_RATE // 2))
+        start = int(rng.integers(margin, n_total - length - margin))
         utterances.append((spk, start, start + length, 'some words'))
     utterances.sort(key=lambda u: (u[1], u[0]))
 

@@ -79,4 +79,6 @@ def ref_mismatches():
     found = []
     yield found
     print('reference-channel mismatches:', found)
-    assert len(found) <= 3, found
+    # one is known and certified ((D, K) = (24, 2): one point source on 24 microphones,
+    # cond(Phi_N) = 3e18, a last-bit move of 5e46 -- DESIGN.md section 4); a second one is news
+    assert len(found) <= 1, found

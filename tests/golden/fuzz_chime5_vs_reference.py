@@ -22,6 +22,15 @@ import make_golden_session as mgs  # noqa: E402
 KEYS = ('start', 'end', 'num_samples', 'start_orig', 'end_orig', 'num_samples_orig')
 
 
+class _NumpyStaging:
+    """Stands in for ops.HostStaging (page-locked memory needs a GPU): same `shape` contract."""
+
+    def shape(self, D, N, K, N_act):
+        self.obs = np.full((D, N), 12345, dtype=np.int16)
+        self.act = np.full((K, N_act), 7, dtype=np.uint8)
+        return self.obs, self.act
+
+
 def bookkeeping(enh, session_id, chime6, probe):
     it = enh.get_iterator(session_id)
     examples = [{'example_id': ex['example_id'], 'speaker_id': ex['speaker_id'],
@@ -36,15 +45,30 @@ def bookkeeping(enh, session_id, chime6, probe):
     cut = {}
     for idx in probe:
         if idx < len(it):
+            loader = ()
             if hasattr(enh, '_prepare_example'):      # pb_chime5_amd: the host side alone (no GPU here)
-                obs, ex_act, _ = enh._prepare_example(it[idx])
+                obs, ex_act, speaker = enh._prepare_example(it[idx])
+                # ... and the session driver's loader (WAV slices straight into int16 rows,
+                # activity tracks sliced into uint8 rows) must hand the device the same thing
+                from pb_chime5_amd.io.wav_slices import WavSliceReader
+                st, reader = _NumpyStaging(), WavSliceReader()
+                target, _, _, keep = enh._prepare_into(it[idx], st, reader)
+                reader.close()
+                same = (st.obs.shape == obs.shape and np.array_equal(st.obs / 2.0 ** 15, obs)
+                        and np.array_equal(st.act, np.array(list(ex_act.values())).astype(np.uint8))
+                        and target == tuple(ex_act.keys()).index(speaker))
+                x = np.arange(st.obs.shape[-1] + 1000)
+                trimmed = enh._trim_context(x, it[idx])
+                same = same and np.array_equal(trimmed, x if keep is None else x[keep[0]:keep[1]])
+                if not same:
+                    loader = ('the session loader differs from _prepare_example',)
             else:
                 enh.enhance_example(it[idx], debug=True)
                 loc = enh.enhance_example_locals
                 obs, ex_act = loc['obs'], loc['ex_array_activity']
             cut[idx] = (tuple(obs.shape), list(ex_act.keys()),
                         np.packbits(np.array(list(ex_act.values())), axis=-1).tobytes(),
-                        float(np.abs(obs).sum()))
+                        float(np.abs(obs).sum())) + loader
     return examples, act, cut
 
 
@@ -78,7 +102,7 @@ def main():
                           utts_per_speaker=int(rng.integers(1, 6)), num_redacted=int(rng.integers(0, 4)),
                           rir_taps=64)
             enhancer = dict(context_samples=int(rng.integers(0, 40000)),
-                            multiarray=[False, True, 'outer_array_mics'][int(rng.integers(0, 3))],
+                            multiarray=[False, True, 'outer_array_mics', 'first_array_mics'][int(rng.integers(0, 4))],
                             wpe=False, bss_iterations=1, bss_iterations_post=1)
             root = tmp / f'corpus{case}'
             json_path = write_chime5_corpus(root, **corpus, chime6=chime6)

@@ -340,7 +340,11 @@ def _scene(rng, D, T, F, K):
     (7, 200, 4, 4, 6, 1), (24, 400, 3, 5, 10, 1), (12, 333, 3, 5, 8, 1), (5, 65, 2, 1, 3, 1),
     (29, 150, 2, 3, 3, 1), (6, 129, 3, 8, 4, 1),
     # more than 8 classes (pb_bss allows K < 20): the M-step runs in class groups
-    (8, 300, 3, 9, 4, 1), (24, 260, 2, 12, 3, 1), (12, 400, 2, 19, 3, 0), (4, 500, 3, 19, 3, 2)])
+    (8, 300, 3, 9, 4, 1), (24, 260, 2, 12, 3, 1), (12, 400, 2, 19, 3, 0), (4, 500, 3, 19, 3, 2),
+    # one array, K <= 6: the one-launch kernel (em_onchip4_kernel) -- several 256-frame chunks,
+    # a ragged last one, every class count it is built for, masked / unmasked post steps
+    (4, 700, 3, 5, 6, 1), (4, 513, 2, 6, 4, 0), (4, 257, 2, 2, 5, 2), (4, 1030, 2, 4, 3, 1),
+    (4, 256, 2, 5, 1, 1)])
 def test_cacgmm_matches_oracle(gpu_ctx, D, T, F, K, iters, post):
     from pb_chime5_amd import ops
     rng = np.random.default_rng(D + T + K)
@@ -350,6 +354,31 @@ def test_cacgmm_matches_oracle(gpu_ctx, D, T, F, K, iters, post):
     assert got.shape == want.shape == (K, T, F)
     assert np.max(np.abs(got - want)) < 1e-7
     assert np.max(np.abs(got.sum(axis=0) - 1)) < 1e-12 or post == 0
+
+
+@pytest.mark.parametrize('K,post', [(3, 1), (5, 0), (6, 2)])
+def test_cacgmm_one_array_kernel_equals_three_launch_path(gpu_ctx, monkeypatch, K, post):
+    """D = 4: the one-launch EM (power-form softmax, sums in another order, model through the
+    scalar cache) against the E-step / M-step / model-update launches of every other channel
+    count (GSS_EM_UNFUSED=1) and against its own eigendecomposition path (GSS_FORCE_EIGH=1):
+    the same posteriors to rounding; the oracle is the referee for all of them."""
+    from pb_chime5_amd import ops
+    rng = np.random.default_rng(40 + K)
+    Y, act = _scene(rng, 4, 900, 4, K)
+    one = ops.cacgmm_posteriors(Y, act, 8, post, ctx=gpu_ctx)
+    monkeypatch.setenv('GSS_EM_UNFUSED', '1')
+    three = ops.cacgmm_posteriors(Y, act, 8, post, ctx=gpu_ctx)
+    monkeypatch.delenv('GSS_EM_UNFUSED')
+    monkeypatch.setenv('GSS_FORCE_EIGH', '1')
+    eigh = ops.cacgmm_posteriors(Y, act, 8, post, ctx=gpu_ctx)
+    monkeypatch.delenv('GSS_FORCE_EIGH')
+    want = oracle.gss_block(Y, act, 8, post)
+    print(f'K={K} post={post}: one launch vs three {np.max(np.abs(one - three)):.1e}, vs eigh path '
+          f'{np.max(np.abs(one - eigh)):.1e}, vs oracle {np.max(np.abs(one - want)):.1e} '
+          f'(three launches vs oracle {np.max(np.abs(three - want)):.1e})')
+    assert np.max(np.abs(one - three)) < 1e-9
+    assert np.max(np.abs(one - eigh)) < 1e-8
+    assert np.max(np.abs(one - want)) < 1e-7
 
 
 def test_cacgmm_class_with_fewer_frames_than_channels(gpu_ctx):

@@ -1,0 +1,37 @@
+#!/bin/bash
+# The fuzz campaign behind DESIGN.md section 4, reproducible: every sweep with fixed seeds and
+# case counts, the one-line tallies collected into ONE tracked summary
+# (gpurun_out/fuzz_TAG/summary.txt -> copy to profiles/TAG_fuzz_summary.txt).  Runs on a GPU box:
+#     gpurun --timeout 2400 -- 'bash tools/fuzz_all.sh r04'
+# The host-side fuzzers against the REFERENCE'S OWN code (tests/golden/fuzz_*_vs_reference.py)
+# need /root/reference and run in the build container: tools/fuzz_reference.sh.
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=${1:-r04}
+O=$R/gpurun_out/fuzz_$TAG
+mkdir -p $O
+cd $R
+S=$O/summary.txt
+echo "fuzz campaign $TAG: $(git -C $R rev-parse --short HEAD 2>/dev/null || echo 'snapshot') on $(date -u +%Y-%m-%dT%H:%MZ)" > $S
+run() { # name, command...
+  local name=$1; shift
+  echo "== $name: $*" >> $S
+  ( "$@" > $O/$name.log 2>&1; echo "exit status $?" >> $O/$name.log )
+  grep -E "fuzz:|fuzz: seed|failures|passed|failed|error|exit status|reference-channel mismatches" $O/$name.log | tail -4 >> $S
+}
+# whole pipeline, wide parameter space (tests/fuzz_params.py), every case also through the
+# block-by-block orchestration
+for seed in 4101 4102 4103; do
+  run pipeline_$seed env GSS_FUZZ_SEED=$seed GSS_FUZZ_CASES=250 GSS_FUZZ_WIDE=1 timeout 900 \
+      python -m pytest tests/test_gpu_pipeline.py -m gpu -q -s -k test_random_shapes_against_oracle
+done
+run stft python tools/fuzz_stft.py 41 600
+run wpe python tools/fuzz_wpe.py 42 400
+run wpe_one_array env GSS_FUZZ_D=4 python tools/fuzz_wpe.py 43 200        # P folded into R's last column tile
+run wpe_24 env GSS_FUZZ_D=24 python tools/fuzz_wpe.py 44 60               # persistent LDS-DMA correlation
+run wpe_20 env GSS_FUZZ_D=20 python tools/fuzz_wpe.py 45 60
+run bf python tools/fuzz_bf.py 46 600
+run em python tools/fuzz_em.py 47 700
+run em_one_array env GSS_FUZZ_D=4 GSS_FUZZ_KMAX=6 GSS_FUZZ_TMAX=1200 python tools/fuzz_em.py 48 500   # em_onchip4_kernel
+for seed in 49 50 51; do run session_$seed python tools/fuzz_session.py $seed 24; done
+run session_gev python tools/fuzz_session.py 52 24 gev_ban
+cat $S

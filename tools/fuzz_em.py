@@ -7,6 +7,7 @@ brute force share LAPACK's eigh, so d underestimates that drift (worst ratio see
 cases: 16, at absolute differences below 1e-6; the convergence bug this sweep family found sat
 at 7000).
     python tools/fuzz_em.py [SEED] [CASES]"""
+import os
 import sys
 import warnings
 from pathlib import Path
@@ -31,6 +32,15 @@ def main():
     for case in range(cases):
         D = int(rng.integers(1, 33)); K = int(rng.integers(1, 20))
         T = int(rng.integers(8, 300)); F = int(rng.integers(1, 4))
+        # GSS_FUZZ_D / GSS_FUZZ_KMAX / GSS_FUZZ_TMAX aim the sweep at one kernel family (the
+        # draws above are still consumed): e.g. D = 4, K <= 6, up to 1200 frames = the one-launch
+        # kernel of the one-array regime over several 256-frame chunks
+        if os.environ.get('GSS_FUZZ_D'):
+            D = int(os.environ['GSS_FUZZ_D'])
+        if os.environ.get('GSS_FUZZ_KMAX'):
+            K = 1 + K % int(os.environ['GSS_FUZZ_KMAX'])
+        if os.environ.get('GSS_FUZZ_TMAX'):
+            T = 8 + (T * 7919) % int(os.environ['GSS_FUZZ_TMAX'])
         it = int(rng.integers(1, 6)); post = int(rng.integers(0, 3))
         act = np.zeros((K, T), bool)
         act[-1] = True                                           # garbage class

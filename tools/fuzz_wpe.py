@@ -2,6 +2,7 @@
 taps * D lands on and around the block boundaries of the Cholesky solve (48, 96, ... and the 16-row
 panels inside), frame counts around the 64-frame chunks of the correlation kernel, one to three
 iterations, with and without a PSD context:  python tools/fuzz_wpe.py [SEED] [CASES]"""
+import os
 import sys
 from pathlib import Path
 
@@ -23,6 +24,8 @@ def main():
     ctx = ops.default_context()
     for case in range(cases):
         D = int(rng.integers(1, 31))
+        if os.environ.get('GSS_FUZZ_D'):      # aim at one correlation kernel family
+            D = int(os.environ['GSS_FUZZ_D'])
         taps = int(rng.integers(1, 11))
         if rng.integers(0, 3) == 0:       # aim at a block boundary
             target = int(rng.choice([16, 32, 48, 64, 96, 144, 192, 240, 288])) + int(rng.integers(-1, 2))
