@@ -656,6 +656,34 @@ __device__ __forceinline__ TriSlots tri_slots(int D, int lane) {
     return t;
 }
 
+// The same from a table (tri_table_kernel: packed[e] for the row-major packed order, then
+// packed[NE + e'] for the column-major order e' = d2 (d2 + 1) / 2 + d1): em_chol is bound by
+// instruction issue (6800 instructions per class matrix at D = 24, tools/chol_trace.py) and
+// the closed form above was 800 of them.
+__global__ void tri_table_kernel(int D, int *__restrict__ tab) {
+    const int NE = tri_count(D);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < NE; e += gridDim.x * blockDim.x) {
+        int d1, d2;
+        tri_unpack(e, D, d1, d2);
+        tab[e] = d1 << 8 | d2;
+        int c = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);     // column of e'
+        while (c * (c + 1) / 2 > e) --c;
+        while ((c + 1) * (c + 2) / 2 <= e) ++c;
+        tab[NE + e] = (e - c * (c + 1) / 2) << 8 | c;
+    }
+}
+__device__ __forceinline__ TriSlots tri_slots_tab(const int *__restrict__ tab, int NE, int lane) {
+    TriSlots t;
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        const int e = lane + 64 * s;
+        t.d12[s] = e < NE ? tab[e] : -1;
+    }
+    return t;
+}
+// packed entries a wave needs for D <= 8 NR channels: ceil(D (D + 1) / 2 / 64)
+__host__ __device__ constexpr int cov_slots_for(int NR) { return NR <= 1 ? 1 : NR == 2 ? 3 : NR == 3 ? 5 : 9; }
+
 // sum over the E-step's partial sums of gamma_k: one load per lane and a fixed reduction
 // tree (a serial loop is a chain of dependent L2 round trips, one per partial sum).
 __device__ inline double sum_gamma(const double *__restrict__ Sg, int sg_nch, int K, int k, int f,
@@ -672,33 +700,42 @@ __device__ inline double sum_gamma(const double *__restrict__ Sg, int sg_nch, in
 constexpr int COV_SLOTS = 9;
 static_assert(COV_SLOTS == sizeof(TriSlots::d12) / sizeof(int), "TriSlots");
 
+template <int NS = COV_SLOTS>
 __device__ inline double reduce_covariance(const cplx *__restrict__ Bp, int nch, int D, int K,
                                            int k, int f, double den, cplx (&vals)[COV_SLOTS],
                                            int lane, const TriSlots &ts) {
     const int NE = tri_count(D);
     double tr = 0.0;
+    // CB chunks of ALL slots are requested before any of them is added (slot after slot was
+    // one memory round trip per slot: 30 % of em_chol's time at D = 24); every entry is still
+    // summed in ascending chunk order
+    constexpr int CB = NS <= 3 ? 8 : NS <= 5 ? 6 : 2;
 #pragma unroll
-    for (int s = 0; s < COV_SLOTS; ++s) {
-        const int e = lane + 64 * s;
-        cplx v = c_make(0.0, 0.0);
-        if (e < NE) {
-            const cplx *src = Bp + ((int64_t)f * nch * K + k) * NE + e;
-            for (int c = 0; c < nch; c += 8) {
-                cplx t[8];
+    for (int s = 0; s < COV_SLOTS; ++s) vals[s] = c_make(0.0, 0.0);
+    const cplx *src = Bp + ((int64_t)f * nch * K + k) * NE + lane;
+    for (int c = 0; c < nch; c += CB) {
+        cplx t[NS][CB];
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    t[j] = c + j < nch ? src[(int64_t)(c + j) * K * NE] : c_make(0.0, 0.0);
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v = c_add(v, t[j]);
-            }
-            v.x = ((double)D * v.x) / den;
-            v.y = ((double)D * v.y) / den;
+            for (int j = 0; j < CB; ++j)
+                t[s][j] = (lane + 64 * s < NE && c + j < nch) ? src[(int64_t)(c + j) * K * NE + 64 * s]
+                                                              : c_make(0.0, 0.0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int j = 0; j < CB; ++j) vals[s] = c_add(vals[s], t[s][j]);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (lane + 64 * s < NE) {
+            vals[s].x = ((double)D * vals[s].x) / den;
+            vals[s].y = ((double)D * vals[s].y) / den;
         }
-        vals[s] = v;
     }
     // trace: diagonal entries
 #pragma unroll
-    for (int s = 0; s < COV_SLOTS; ++s) {
+    for (int s = 0; s < NS; ++s) {
         const int p = ts.d12[s];
         if (p >= 0 && (p >> 8) == (p & 255)) {
             vals[s].y = 0.0;
@@ -710,10 +747,11 @@ __device__ inline double reduce_covariance(const cplx *__restrict__ Bp, int nch,
 
 // Scatter the reduced entries into LDS: lower triangle (conjugated), optionally the
 // mirrored upper one, with `shift` subtracted from the diagonal.
+template <int NS = COV_SLOTS>
 __device__ inline void store_covariance(const cplx (&vals)[COV_SLOTS], int D, double shift,
                                         bool full, cplx *A, int ld, int lane, const TriSlots &ts) {
 #pragma unroll
-    for (int s = 0; s < COV_SLOTS; ++s) {
+    for (int s = 0; s < NS; ++s) {
         const int p = ts.d12[s];
         if (p >= 0) {
             const int d1 = p >> 8, d2 = p & 255;
@@ -745,23 +783,41 @@ __device__ inline void store_covariance(const cplx (&vals)[COV_SLOTS], int D, do
 // the packed upper triangle of B (entry e = lane + 64 s).  Writes Mq(:, k) and ln det and
 // returns whether the no-floor certificate holds; A = D * (8 NR + 1) complex + D doubles
 // of LDS owned by this wave.
+#ifdef GSS_CHOL_TRACE
+// tools/chol_trace.py: shader-clock stamps of em_chol_kernel's wave per phase
+__device__ long long g_chol_phase[4096 * 10];
+extern "C" int gss_debug_chol_phase(long long *host, int entries) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_chol_phase), sizeof(long long) * 10 * entries);
+}
+#define CHOL_STAMP(slot)                                                              \
+    do {                                                                              \
+        const int wg_ = blockIdx.y * gridDim.x + blockIdx.x;                          \
+        if (threadIdx.x == 0 && wg_ < 4096) g_chol_phase[wg_ * 10 + (slot)] = clock64(); \
+    } while (0)
+#else
+#define CHOL_STAMP(slot)
+#endif
+
 template <int NR>
 __device__ __forceinline__ bool class_update_chol(const cplx (&vals)[COV_SLOTS], int D, int K,
                                                   double eig_floor, cplx *A, int lane,
                                                   cplx *__restrict__ Mq_fk,
                                                   double *__restrict__ logdet_fk,
-                                                  const TriSlots &ts) {
+                                                  const TriSlots &ts,
+                                                  const int *__restrict__ tab_cm = nullptr) {
     constexpr int ld = 8 * NR + 1;
+    constexpr int NS = cov_slots_for(NR);
     double *dinv = reinterpret_cast<double *>(A + D * ld);
     double nb2 = 0.0;   // ||B||_F^2 from the packed upper triangle
 #pragma unroll
-    for (int s = 0; s < COV_SLOTS; ++s) {
+    for (int s = 0; s < NS; ++s) {
         const int p = ts.d12[s];
         if (p >= 0)
             nb2 += ((p >> 8) == (p & 255) ? 1.0 : 2.0) * (vals[s].x * vals[s].x + vals[s].y * vals[s].y);
     }
     nb2 = wave_sum(nb2);
-    store_covariance(vals, D, 0.0, true, A, ld, lane, ts);
+    CHOL_STAMP(4);
+    store_covariance<NS>(vals, D, 0.0, true, A, ld, lane, ts);
     wave_sync();
     const int tx = lane & 7, ty = lane >> 3;
     cplx reg[NR][NR];
@@ -773,20 +829,29 @@ __device__ __forceinline__ bool class_update_chol(const cplx (&vals)[COV_SLOTS],
             reg[a][b] = (kk >= i && kk < D) ? A[i * ld + kk] : c_make(0.0, 0.0);
         }
     wave_sync();
+    CHOL_STAMP(5);
     if (!chol_inverse_sweep<8, NR, true>(reg, D, A, ld, dinv, tx, ty)) return false;
+    CHOL_STAMP(6);
     double ldv = 0.0;   // ln det B = 2 sum ln U_ii
     for (int i = lane; i < D; i += 64) ldv -= 2.0 * log(dinv[i]);
     ldv = wave_sum(ldv);
+    CHOL_STAMP(7);
     // W = U^-H from the unscaled rows of the sweep: W[j][k] = A[j][k] dinv[j] (k < j),
     // W[j][j] = dinv[j].  B^-1 = W^H W :  (d1,d2) = sum_{j >= d2} conj(W[j][d1]) W[j][d2]
     //   = dinv[d2]^2 (d1 == d2 ? 1 : conj(A[d2][d1]))
     //     + sum_{j > d2} dinv[j]^2 conj(A[j][d1]) A[j][d2]
+    // An entry costs D - 1 - d2 terms.  With the table, slot s of a lane is entry
+    // lane + 64 s of the COLUMN-major packed order, which sorts the entries by that count: the
+    // trips of a slot (the longest of its 64 lanes) add up to 45 at D = 24 instead of 115 in
+    // row-major order -- same terms, same order per entry, a third of the instructions.
     double ni2 = 0.0;
+    const int NE = tri_count(D);
 #pragma unroll
-    for (int s = 0; s < COV_SLOTS; ++s) {
-        const int p = ts.d12[s];
+    for (int s = 0; s < NS; ++s) {
+        const int p = tab_cm ? (lane + 64 * s < NE ? tab_cm[lane + 64 * s] : -1) : ts.d12[s];
         if (p < 0) continue;
-        const int e = lane + 64 * s, d1 = p >> 8, d2 = p & 255;
+        const int d1 = p >> 8, d2 = p & 255;
+        const int e = tab_cm ? tri_index(d1, d2, D) : lane + 64 * s;
         const double s2 = dinv[d2] * dinv[d2];
         cplx v = d1 == d2 ? c_make(s2, 0.0) : c_scale(c_conj(A[d2 * ld + d1]), s2);
         for (int j = d2 + 1; j < D; ++j) {
@@ -805,6 +870,7 @@ __device__ __forceinline__ bool class_update_chol(const cplx (&vals)[COV_SLOTS],
         Mq_fk[(int64_t)e * K] = v;
     }
     ni2 = wave_sum(ni2);
+    CHOL_STAMP(8);
     if (lane == 0) *logdet_fk = ldv;
     const double bound = 0.5 / eig_floor;
     return isfinite(ni2) && nb2 * ni2 < bound * bound;
@@ -868,24 +934,29 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
                                                      int force_eigh, cplx *__restrict__ Mq,
                                                      double *__restrict__ logdet,
                                                      double *__restrict__ pi,
-                                                     int *__restrict__ need_eigh) {
+                                                     int *__restrict__ need_eigh,
+                                                     const int *__restrict__ tri_tab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NE = tri_count(D);
     cplx *A = reinterpret_cast<cplx *>(smem);                  // D * (8 NR + 1) + D doubles
     const int k = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
 
+    CHOL_STAMP(0);
+    const TriSlots ts = tri_slots_tab(tri_tab, NE, lane);
     const double sg = sum_gamma(Sg, sg_nch, K, k, f, lane);
     const double den = fmax(sg, GSS_TINY);
     if (lane == 0) pi[f * K + k] = sg / (double)T;
-
-    const TriSlots ts = tri_slots(D, lane);
+    CHOL_STAMP(1);
+    CHOL_STAMP(2);
     cplx vals[COV_SLOTS];
-    const double tr = reduce_covariance(Bp, nch, D, K, k, f, den, vals, lane, ts);
+    const double tr = reduce_covariance<cov_slots_for(NR)>(Bp, nch, D, K, k, f, den, vals, lane, ts);
+    CHOL_STAMP(3);
     bool fast = !force_eigh && tr > 0.0 && isfinite(tr);
     if (fast)
         fast = class_update_chol<NR>(vals, D, K, eig_floor, A, lane, Mq + (int64_t)f * NE * K + k,
-                                     logdet + f * K + k, ts);
+                                     logdet + f * K + k, ts, tri_tab + NE);
     if (lane == 0) need_eigh[f * K + k] = fast ? 0 : 1;
+    CHOL_STAMP(9);
 }
 
 // Eigendecomposition path for the flagged matrices; overwrites their Mq / ln det.
@@ -895,14 +966,15 @@ __global__ __launch_bounds__(64) void em_eigh_kernel(const cplx *__restrict__ Bp
                                                      int K, double eig_floor,
                                                      const int *__restrict__ need_eigh,
                                                      cplx *__restrict__ Mq,
-                                                     double *__restrict__ logdet) {
+                                                     double *__restrict__ logdet,
+                                                     const int *__restrict__ tri_tab) {
     const int k = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
     if (!need_eigh[f * K + k]) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NE = tri_count(D);
     const double sg = sum_gamma(Sg, sg_nch, K, k, f, lane);
     const double den = fmax(sg, GSS_TINY);
-    const TriSlots ts = tri_slots(D, lane);
+    const TriSlots ts = tri_slots_tab(tri_tab, NE, lane);
     cplx vals[COV_SLOTS];
     reduce_covariance(Bp, nch, D, K, k, f, den, vals, lane, ts);
     class_update_eigh(vals, D, K, eig_floor, reinterpret_cast<cplx *>(smem), lane,
@@ -1541,6 +1613,7 @@ size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K) {
     b += align_up(sizeof(cplx) * (size_t)F * nch * K * NE);      // Bp
     b += align_up(sizeof(double) * (size_t)F * nch * K);         // Sg
     b += align_up(sizeof(int) * (size_t)F * K);                  // need_eigh
+    b += align_up(sizeof(int) * 2 * NE);                         // tri_tab
     b += align_up(sizeof(cplx) * (size_t)F * D * T);             // Yn (register-form E-step)
     b += align_up(sizeof(double) * (size_t)F * ((T + 63) / 64 + 4) * K);
     b += 2 * align_up(16 * (2 + 16 * (K * 17) + 2 * NE * K + 2 * K + 8 + 16 * NE * K));   // em_onchip coop
@@ -1612,7 +1685,13 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     const size_t eigh_lds = (sizeof(cplx) * 2 * m * m + sizeof(double) * m + 15) / 16 * 16;
     const int force_eigh = getenv("GSS_FORCE_EIGH") != nullptr;
     int *need_eigh = arena_alloc_t<int>(ctx, (size_t)F * K);
-    GSS_REQUIRE(ctx, need_eigh, GSS_ERR_NOMEM, "cacgmm workspace");
+    // (d1, d2) of the packed triangle, row-major and column-major order (em_chol / em_eigh)
+    int *tri_tab = arena_alloc_t<int>(ctx, 2 * (size_t)NE);
+    GSS_REQUIRE(ctx, need_eigh && tri_tab, GSS_ERR_NOMEM, "cacgmm workspace");
+    if (!(D == 4 && K >= 2 && K <= 6 && reg && iterations > 0 && getenv("GSS_EM_UNFUSED") == nullptr)) {
+        hipLaunchKernelGGL(tri_table_kernel, dim3(1), dim3(256), 0, ctx->stream, D, tri_tab);
+        GSS_LAUNCH_CHECK(ctx, "tri_table_kernel");
+    }
 
     int sg_nch = nch_lds;
     auto eig = [&]() -> int {
@@ -1623,13 +1702,13 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
             auto kern = nr <= 1 ? em_chol_kernel<1> : nr == 2 ? em_chol_kernel<2>
                         : nr == 3 ? em_chol_kernel<3> : em_chol_kernel<4>;
             hipLaunchKernelGGL(kern, dim3(K, F), dim3(64), lds, ctx->stream, a.Bp, a.Sg, a.nch,
-                               sg_nch, D, K, T, 1e-10, force_eigh, Mq, logdet, pi, need_eigh);
+                               sg_nch, D, K, T, 1e-10, force_eigh, Mq, logdet, pi, need_eigh, tri_tab);
             GSS_LAUNCH_CHECK(ctx, "em_chol_kernel");
         }
         {
             GSS_PROF(ctx, "em_eigh");
             hipLaunchKernelGGL(em_eigh_kernel, dim3(K, F), dim3(64), eigh_lds, ctx->stream, a.Bp,
-                               a.Sg, a.nch, sg_nch, D, K, 1e-10, need_eigh, Mq, logdet);
+                               a.Sg, a.nch, sg_nch, D, K, 1e-10, need_eigh, Mq, logdet, tri_tab);
             GSS_LAUNCH_CHECK(ctx, "em_eigh_kernel");
         }
         return GSS_OK;
