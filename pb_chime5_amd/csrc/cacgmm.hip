@@ -1011,14 +1011,19 @@ __device__ __forceinline__ double row16_sum(double v) {      // total in lane 15
 
 constexpr int OC_FRAMES = 256;
 
+#ifndef GSS_EM4_ABL
+#define GSS_EM4_ABL 0      // timing-only ablations of em_onchip4_kernel (wrong results)
+#endif
 #ifdef GSS_EM4_TRACE
 // tools/em4_trace.py: shader cycles wave 0 of every workgroup spends per phase
 __device__ long long g_em4_phase[1024 * 6];
 extern "C" int gss_debug_em4_phase(long long *host, int entries) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_em4_phase), sizeof(long long) * 6 * entries);
 }
-#define EM4_T(var) const long long var = clock64()
-#define EM4_ADD(slot, d) if (tid == 0 && blockIdx.x < 1024) g_em4_phase[blockIdx.x * 6 + (slot)] += (d)
+// (accumulated in registers, written once at the end: a global read-modify-write per stamp
+// cost more than the phases it measured)
+#define EM4_T(var) const long long var = __builtin_readcyclecounter()
+#define EM4_ADD(slot, d) em4_acc[slot] += (d)
 #else
 #define EM4_T(var)
 #define EM4_ADD(slot, d)
@@ -1056,17 +1061,130 @@ __device__ __forceinline__ void coop_wait(int *flag, int value) {       // one t
         __builtin_amdgcn_s_sleep(16);
 }
 
+// One class per LANE (D = 4): Cholesky factor B = U^H U, X = U^-1, B^-1 = X X^H, ln det and
+// the no-floor certificate of class_update_chol, all in the registers of one lane -- the
+// generic wave-cooperative sweep (8 x 8 lane grid, LDS row ring, one wave per class) took
+// 13 - 20 % of the one-launch kernel for 4 x 4 matrices.  A single lane is a chain of
+// dependent instructions at ~16 cycles each, so everything that is not the factorisation is
+// kept out of it: the 16 divisions by sum gamma are done by 16 threads beforehand and
+// ln det = ln (product of the pivots) is one logarithm (the pivots of the trace-D matrix lie
+// in [1e-10 D, D] or the certificate fails: no under- or overflow).  `b`: B_k in phase-M order
+// (4 diagonals, then re and im of the six upper entries in walk order); `m`: B_k^-1 in the
+// same order, off-diagonals doubled (the coefficients of q = sum_i m_i P_i).
+__device__ __forceinline__ bool class_update4_lane(const double (&b)[16], double eig_floor,
+                                                   double (&m)[16], double &logdet) {
+    constexpr int D = 4;
+    cplx a[D][D];
+    double nb2 = 0.0, tr = 0.0;
+    {
+        int off = 0;
+#pragma unroll
+        for (int d1 = 0; d1 < D; ++d1)
+#pragma unroll
+            for (int d2 = d1; d2 < D; ++d2) {
+                if (d1 == d2) {
+                    a[d1][d1] = c_make(b[d1], 0.0);
+                    tr += b[d1];
+                    nb2 += b[d1] * b[d1];
+                } else {
+                    a[d1][d2] = c_make(b[D + off], b[D + 6 + off]);
+                    nb2 += 2.0 * (a[d1][d2].x * a[d1][d2].x + a[d1][d2].y * a[d1][d2].y);
+                    ++off;
+                }
+            }
+    }
+    bool ok = tr > 0.0 && isfinite(tr);
+    double di[D], piv = 1.0;
+    cplx U[D][D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const double ajj = a[j][j].x;
+        const bool good = ajj > 0.0 && isfinite(ajj);
+        ok = ok && good;
+        piv *= ajj;
+        di[j] = good ? rsqrt(ajj) : 0.0;
+#pragma unroll
+        for (int k = j + 1; k < D; ++k) U[j][k] = c_scale(a[j][k], di[j]);
+#pragma unroll
+        for (int i = j + 1; i < D; ++i) {
+            a[i][i].x = fma(-U[j][i].x, U[j][i].x, a[i][i].x);
+            a[i][i].x = fma(-U[j][i].y, U[j][i].y, a[i][i].x);
+#pragma unroll
+            for (int k = i + 1; k < D; ++k) {           // a[i][k] -= conj(U[j][i]) U[j][k]
+                a[i][k].x = fma(-U[j][i].x, U[j][k].x, a[i][k].x);
+                a[i][k].x = fma(-U[j][i].y, U[j][k].y, a[i][k].x);
+                a[i][k].y = fma(-U[j][i].x, U[j][k].y, a[i][k].y);
+                a[i][k].y = fma(U[j][i].y, U[j][k].x, a[i][k].y);
+            }
+        }
+    }
+    // X = U^-1 (upper): X[i][i] = di[i], X[i][k] = -di[i] sum_{m = i+1..k} U[i][m] X[m][k]
+    cplx X[D][D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        X[k][k] = c_make(di[k], 0.0);
+#pragma unroll
+        for (int i = k - 1; i >= 0; --i) {
+            cplx s = c_make(0.0, 0.0);
+#pragma unroll
+            for (int mm = i + 1; mm <= k; ++mm) c_fma(s, U[i][mm], X[mm][k]);
+            X[i][k] = c_make(-di[i] * s.x, -di[i] * s.y);
+        }
+    }
+    logdet = ok ? log(piv) : 0.0;
+    double ni2 = 0.0;
+    int off = 0;
+#pragma unroll
+    for (int d1 = 0; d1 < D; ++d1)
+#pragma unroll
+        for (int d2 = d1; d2 < D; ++d2) {
+            cplx v = c_make(0.0, 0.0);
+#pragma unroll
+            for (int j = d2; j < D; ++j) c_fmac(v, X[d1][j], X[d2][j]);
+            if (d1 == d2) {
+                ni2 += v.x * v.x;
+                m[d1] = v.x;
+            } else {
+                ni2 += 2.0 * (v.x * v.x + v.y * v.y);
+                m[D + off] = 2.0 * v.x;
+                m[D + 6 + off] = 2.0 * v.y;
+                ++off;
+            }
+        }
+    const double bound = 0.5 / eig_floor;
+    return ok && isfinite(ni2) && nb2 * ni2 < bound * bound;
+}
+
+// sum over the four lanes of a quad, in every lane (DPP quad_perm)
+__device__ __forceinline__ double quad_sum(double v) {
+    v += dpp_shifted<0xB1, 0xf, 0xf>(v);      // quad_perm:[1,0,3,2]
+    v += dpp_shifted<0x4E, 0xf, 0xf>(v);      // quad_perm:[2,3,0,1]
+    return v;
+}
+
+constexpr int OC_LD = 72;        // doubles per LDS row of a wave's 64 frames (see phase M)
+
 template <int K>
 __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
     constexpr int D = 4, NE = 10, NP = 16;           // NP: real numbers per frame's products
-    // (rows padded by 128 bytes: the four entry rows a wave reads in phase M start in
-    // different halves of the 64 banks)
-    __shared__ __attribute__((aligned(16))) double wS[K][OC_FRAMES];
-    __shared__ __attribute__((aligned(16))) double pS[NP][OC_FRAMES + 16];
+    // Every WAVE owns its 64 frames from phase E through phase M: K weight rows and NP product
+    // rows of its own in LDS, so a chunk needs no workgroup barrier (two per chunk cost a
+    // quarter of the kernel).  Row stride 72 doubles: the lane groups of a ds_read_b128 meet
+    // four different entries `mi`, and 2 * 72 dwords = 9 * 16 puts them 16 banks apart.
+    __shared__ __attribute__((aligned(16))) double ldsS[4][K + NP][OC_LD];
     __shared__ double logdetS[K], piS[K], cS[K], sgS[4][K], bS[K][NP];
-    __shared__ __attribute__((aligned(16))) cplx MqS[NE * K];
+    // the model: row i holds the K coefficients of product P_i in q_k = sum_i m_ik P_i (B_k^-1
+    // in phase-M order, off-diagonals doubled); phase E reads a row with broadcast
+    // ds_read_b128s, two rows ahead of the FMAs that use it
+    constexpr int KP = (K + 1) / 2;
+    __shared__ __attribute__((aligned(16))) double mR[NP][2 * KP];
+    __shared__ __attribute__((aligned(16))) cplx MqS[NE * K];      // (flagged classes: em_eigh's layout)
+    __shared__ int flagS;
+    // scratch of the flagged-class path (one wave per class: Cholesky sweep / Jacobi): the
+    // rows above are idle during the model update
     constexpr int CH_LD = 9;
-    __shared__ __attribute__((aligned(16))) char scratch[4][(2 * 4 * 4 + D * CH_LD) * sizeof(cplx) + 64];
+    constexpr int SCRATCH = (2 * 4 * 4 + D * CH_LD) * sizeof(cplx) + 64;
+    static_assert(SCRATCH <= sizeof(double) * (K + NP) * OC_LD, "scratch aliases a wave's rows");
     const int64_t T = a.T;
     // the last frequency may be shared by coop_g workgroups (OnchipArgs): helper cg takes the
     // chunks cg, cg + coop_g, ...
@@ -1080,19 +1198,15 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const cplx *yf = a.Yn + (int64_t)f * D * T;
-    // B_k^-1 (off-diagonals doubled) of this frequency: written to global memory by the class
-    // updates (vector stores, acknowledged by L2) and read back in phase E through the scalar
-    // data cache -- model rows as SGPR operands of the FMAs, like em_estep_reg_kernel; reading
-    // them from LDS instead was one exposed LDS round trip per triangle entry.  The scalar
-    // cache is invalidated after every update, and the pointer is laundered per iteration so
-    // that the compiler neither hoists the loads out of the iteration loop nor makes them
-    // vector loads.
-    cplx *Mq_rw = coop && cg > 0 ? a.Mq_coop + (int64_t)cg * NE * K : a.Mq + (int64_t)f * NE * K;
-    typedef const double __attribute__((address_space(4))) *const_model_ptr;   // (re, im) pairs
+    double (*wS)[OC_LD] = ldsS[wave];                  // K weight rows of this wave
+    double (*pS)[OC_LD] = ldsS[wave] + K;              // NP product rows of this wave
     const int nsub = (int)((T + OC_FRAMES - 1) / OC_FRAMES);
-    const int mi = tid >> 4, msl = tid & 15;          // phase M: entry number, frame slice
+    const int mi = lane >> 2, msl = lane & 3;         // phase M: entry number, frame slice
     const TriSlots ts = tri_slots(D, lane);
 
+#ifdef GSS_EM4_TRACE
+    long long em4_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
     EM4_T(c_start);
     // fit(I iterations, masked) + fit(post - 1 iterations, unmasked) + predict
     const int n_fit = a.iterations + (a.iterations_post > 1 ? a.iterations_post - 1 : 0);
@@ -1104,9 +1218,6 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
         double acc[K], sg[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) acc[k] = sg[k] = 0.0;
-        unsigned long long mq_bits = (unsigned long long)Mq_rw;
-        asm volatile("" : "+s"(mq_bits));
-        const_model_ptr Mc = (const_model_ptr)mq_bits;
 
         // the frame of chunk sub + 1 is requested before chunk sub is evaluated
         cplx yn[D];
@@ -1121,6 +1232,8 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
         };
         fetch(sub0);
         for (int sub = sub0; sub < nsub; sub += sub_step) {
+            // a wave whose 64 frames lie past the end has nothing to do (wave uniform)
+            if ((int64_t)sub * OC_FRAMES + 64 * wave >= T) break;
             EM4_T(c_a);
             const int64_t t = (int64_t)sub * OC_FRAMES + tid;
             const bool valid = t < T;
@@ -1150,7 +1263,7 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
                         }
                     }
             }
-            double q[K], gam[K];
+            double q[K], gam[K], wgt[K];
             if (first) {
                 // GSS initialisation (core.py:156-160): where(act == 0, 1e-10, act) / sum_k; q = 1
                 double ssum = 0.0;
@@ -1161,24 +1274,34 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
                     ssum += gam[k];
                 }
 #pragma unroll
-                for (int k = 0; k < K; ++k) gam[k] /= ssum;
+                for (int k = 0; k < K; ++k) wgt[k] = gam[k] = gam[k] / ssum;
             } else {
 #pragma unroll
                 for (int k = 0; k < K; ++k) q[k] = 0.0;
-                int e = 0, off = 0;
+                {
+                    // q_k = sum_i m_ik P_i: the K coefficients of row i + 2 are requested
+                    // before the FMAs of row i (LDS returns in order: partial waits)
+                    double2 mb[3][KP];
+                    auto mrow = [&](int i, int slot) {
 #pragma unroll
-                for (int d1 = 0; d1 < D; ++d1)
+                        for (int r = 0; r < KP; ++r)
+                            mb[slot][r] = *reinterpret_cast<const double2 *>(&mR[i][2 * r]);
+                    };
+                    mrow(0, 0);
+                    mrow(1, 1);
 #pragma unroll
-                    for (int d2 = d1; d2 < D; ++d2, ++e) {
-                        const double pr = d1 == d2 ? pv[d1] : pv[D + off];
-                        const double pim = d1 == d2 ? 0.0 : pv[D + 6 + off];
-                        if (d1 != d2) ++off;
+                    for (int i = 0; i < NP; ++i) {
+                        if (i + 2 < NP) mrow(i + 2, (i + 2) % 3);
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
-                            q[k] = fma(Mc[2 * (e * K + k)], pr, q[k]);
-                            q[k] = fma(Mc[2 * (e * K + k) + 1], pim, q[k]);
+#if GSS_EM4_ABL == 2
+                            q[k] = fma(1.0 + 0.125 * (i + k), pv[i], q[k]);
+#else
+                            q[k] = fma(k & 1 ? mb[i % 3][k / 2].y : mb[i % 3][k / 2].x, pv[i], q[k]);
+#endif
                         }
                     }
+                }
                 double ssum = 0.0;
 #ifndef GSS_EM4_LOG_SOFTMAX
                 // pi_k exp(-D ln q_k - ln det_k - max) with D = 4 and no logarithm: relative to
@@ -1189,8 +1312,10 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
                 // common factor between the two forms cancels in the normalisation; it is
                 // bounded below by (1e-10)^(2 D) = 1e-80 -- eigenvalue floor / no-floor
                 // certificate --, so nothing underflows that the log form keeps.
+                // One reciprocal per class serves the ratio and the M-step weight gamma / q,
+                // one more the normalisation: K + 1 divisions per frame instead of 3 K.
                 // -DGSS_EM4_LOG_SOFTMAX builds the log / exp form of em_estep_reg_kernel.
-                double qmin = INFINITY;
+                double qmin = INFINITY, iq[K];
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     q[k] = fmax(fabs(q[k]), GSS_TINY);
@@ -1198,10 +1323,27 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
                 }
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const double r = qmin / q[k], r2 = r * r;
+#if GSS_EM4_ABL == 1
+                    iq[k] = __builtin_amdgcn_rcp(q[k]);
+#else
+                    iq[k] = 1.0 / q[k];
+#endif
+                    const double r = qmin * iq[k], r2 = r * r;
                     gam[k] = (r2 * r2) * cS[k];
                     if (masked) gam[k] *= on[k] ? 1.0 : 0.0;
                     ssum += gam[k];
+                }
+#if GSS_EM4_ABL == 1
+                const double is = __builtin_amdgcn_rcp(fmax(ssum, GSS_TINY));
+#else
+                const double is = 1.0 / fmax(ssum, GSS_TINY);
+#endif
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    gam[k] = gam[k] * is;
+                    if (aff_eps != 0.0) gam[k] = fmin(fmax(gam[k], aff_eps), 1.0 - aff_eps);
+                    // gamma / max(q, 10 tiny)
+                    wgt[k] = gam[k] * (q[k] < 10.0 * GSS_TINY ? 1.0 / (10.0 * GSS_TINY) : iq[k]);
                 }
 #else
                 double lp[K], mx = -INFINITY;
@@ -1217,13 +1359,14 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
                     if (masked) gam[k] *= on[k] ? 1.0 : 0.0;
                     ssum += gam[k];
                 }
-#endif
                 ssum = fmax(ssum, GSS_TINY);
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     gam[k] = gam[k] / ssum;
                     if (aff_eps != 0.0) gam[k] = fmin(fmax(gam[k], aff_eps), 1.0 - aff_eps);
+                    wgt[k] = gam[k] / fmax(q[k], 10.0 * GSS_TINY);
                 }
+#endif
             }
             if (predict) {
 #pragma unroll
@@ -1232,32 +1375,36 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
                 continue;
             }
             EM4_T(c_b);
-            __syncthreads();                  // phase M of the previous chunk is done with LDS
-            EM4_T(c_c);
+#if GSS_EM4_ABL == 3
+#pragma unroll
+            for (int k = 0; k < K; ++k) { acc[k] += wgt[k] * pv[k]; sg[k] += valid ? gam[k] : 0.0; }
+            continue;
+#endif
+            wave_sync();                      // this wave's phase M of the previous chunk has read its rows
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const double wk = first ? gam[k] : gam[k] / fmax(q[k], 10.0 * GSS_TINY);
-                wS[k][tid] = valid ? wk : 0.0;
+                wS[k][lane] = valid ? wgt[k] : 0.0;
                 sg[k] += valid ? gam[k] : 0.0;
             }
 #pragma unroll
-            for (int i = 0; i < NP; ++i) pS[i][tid] = pv[i];
-            __syncthreads();
+            for (int i = 0; i < NP; ++i) pS[i][lane] = pv[i];
+            wave_sync();
             EM4_T(c_d);
-            // ---- phase M: thread (entry i, slice s) adds w_kt P_i(t) for the frame pairs
-            // t = 2 s + 32 j (16-byte LDS reads: one of P, K of w per 2 K FMAs)
-            // (operands of step j + 1 are requested before the FMAs of step j)
+            // ---- phase M: lane (entry mi, slice msl) adds w_kt P_mi(t) for the frame pairs
+            // t = 2 msl + 8 j of the wave's 64 frames (16-byte LDS reads: one of P, K of w --
+            // a broadcast within the 16 lanes of a slice -- per 2 K FMAs; operands of step
+            // j + 1 are requested before the FMAs of step j)
             double2 pb[2], wb[2][K];
             auto mload = [&](int j, int slot) {
-                const int tt = 2 * msl + 32 * j;
+                const int tt = 2 * msl + 8 * j;
                 pb[slot] = *reinterpret_cast<const double2 *>(&pS[mi][tt]);
 #pragma unroll
                 for (int k = 0; k < K; ++k) wb[slot][k] = *reinterpret_cast<const double2 *>(&wS[k][tt]);
             };
             mload(0, 0);
 #pragma unroll
-            for (int j = 0; j < OC_FRAMES / 32; ++j) {
-                if (j + 1 < OC_FRAMES / 32) mload(j + 1, (j + 1) & 1);
+            for (int j = 0; j < 8; ++j) {
+                if (j + 1 < 8) mload(j + 1, (j + 1) & 1);
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     acc[k] = fma(wb[j & 1][k].x, pb[j & 1].x, acc[k]);
@@ -1268,8 +1415,7 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
             {
                 EM4_T(c_e);
                 EM4_ADD(0, c_b - c_a);     // phase E
-                EM4_ADD(1, c_c - c_b);     // barrier 1
-                EM4_ADD(2, c_d - c_c);     // LDS stores + barrier 2
+                EM4_ADD(2, c_d - c_b);     // LDS stores
                 EM4_ADD(3, c_e - c_d);     // phase M
             }
 #endif
@@ -1277,19 +1423,33 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
         if (predict) break;
         EM4_T(c_f);
 
-        // ---- the iteration's sums: B_k entries (K x 16 real numbers) and sum_t gamma_kt
+        // ---- the iteration's sums: B_k entries (K x 16 real numbers) and sum_t gamma_kt:
+        // over the four slices of a wave on the DPP network, over the waves through LDS
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const double tot = row16_sum(acc[k]);
-            if (msl == 15) bS[k][mi] = tot;
+            const double tot = quad_sum(acc[k]);
+            if (msl == 0) (&ldsS[wave][0][0])[k * NP + mi] = tot;     // (its own rows: phase M is done)
             const double g = wave_sum(sg[k]);
             if (lane == 0) sgS[wave][k] = g;
         }
         __syncthreads();
+        static_assert(K * NP <= 2 * OC_LD, "the wave sums fit the first rows");
         bool update = true;
-        if (coop) {
+        if (!coop) {
+            // B_k = D sum / max(sum gamma, tiny): one entry per thread
+            if (tid < K * NP) {
+                const int k = tid / NP;
+                const double sgk = (sgS[0][k] + sgS[1][k]) + (sgS[2][k] + sgS[3][k]);
+                const double tot = ((&ldsS[0][0][0])[tid] + (&ldsS[1][0][0])[tid]) +
+                                   ((&ldsS[2][0][0])[tid] + (&ldsS[3][0][0])[tid]);
+                bS[k][tid % NP] = ((double)D * tot) / fmax(sgk, GSS_TINY);
+            }
+        } else {
             // every helper publishes its sums; helper 0 adds them up in helper order
-            if (tid < K * NP) coop_store(coop_part + (size_t)cg * PART + tid, bS[tid / NP][tid % NP]);
+            if (tid < K * NP)
+                coop_store(coop_part + (size_t)cg * PART + tid,
+                           ((&ldsS[0][0][0])[tid] + (&ldsS[1][0][0])[tid]) +
+                               ((&ldsS[2][0][0])[tid] + (&ldsS[3][0][0])[tid]));
             else if (tid < PART)
                 coop_store(coop_part + (size_t)cg * PART + tid,
                            (sgS[0][tid - K * NP] + sgS[1][tid - K * NP]) +
@@ -1301,97 +1461,129 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
             if (update) {
                 if (tid == 0) coop_wait(coop_flags, a.coop_g * (it + 1));
                 __syncthreads();
-                if (tid < PART) {
-                    double tot = 0.0;
+                double tot = 0.0;
+                if (tid < PART)
                     for (int h = 0; h < a.coop_g; ++h) tot += coop_load(coop_part + (size_t)h * PART + tid);
-                    if (tid < K * NP) bS[tid / NP][tid % NP] = tot;
-                    else {
-                        sgS[0][tid - K * NP] = tot;
-                        sgS[1][tid - K * NP] = sgS[2][tid - K * NP] = sgS[3][tid - K * NP] = 0.0;
-                    }
+                if (tid >= K * NP && tid < PART) {
+                    sgS[0][tid - K * NP] = tot;
+                    sgS[1][tid - K * NP] = sgS[2][tid - K * NP] = sgS[3][tid - K * NP] = 0.0;
                 }
                 __syncthreads();
+                if (tid < K * NP) bS[tid / NP][tid % NP] = ((double)D * tot) / fmax(sgS[0][tid / NP], GSS_TINY);
             }
         }
-        // ---- model update: wave w takes classes w, w + 4 (one wave per class matrix, as em_chol)
-        if (update)
-        for (int k = wave; k < K; k += 4) {
+        if (tid == 0) flagS = 0;
+        __syncthreads();
+        // ---- model update: lane k of wave 0 takes class k (class_update4_lane); classes whose
+        // factorisation breaks down or that fail the no-floor certificate are redone by one
+        // wave each with the eigendecomposition of em_eigh
+        EM4_T(c_u0);
+        if (update && wave == 0 && lane < K) {
+            const int k = lane;
             const double sgk = (sgS[0][k] + sgS[1][k]) + (sgS[2][k] + sgS[3][k]);
-            const double den = fmax(sgk, GSS_TINY);
-            if (lane == 0) piS[k] = sgk / (double)T;
-            // packed upper triangle (row major): diagonals are entries 0, 4, 7, 9 (slots 0-3 of
-            // bS), the six others in walk order (re: slots 4-9, im: slots 10-15)
-            cplx vals[COV_SLOTS];
+            piS[k] = sgk / (double)T;
+            double b[NP], m[NP], ld;
 #pragma unroll
-            for (int s2 = 0; s2 < COV_SLOTS; ++s2) vals[s2] = c_make(0.0, 0.0);
-            double tr = 0.0;
-            if (lane < NE) {
-                const int p = ts.d12[0], d1 = p >> 8, d2 = p & 255;
-                if (d1 == d2) {
-                    vals[0] = c_make(((double)D * bS[k][d1]) / den, 0.0);
-                    tr = vals[0].x;
-                } else {
-                    const int off = lane - d1 - 1;          // entries before it minus diagonals
-                    vals[0] = c_make(((double)D * bS[k][D + off]) / den,
-                                     ((double)D * bS[k][D + 6 + off]) / den);
+            for (int i = 0; i < NP; ++i) b[i] = bS[k][i];
+#if GSS_EM4_ABL == 4
+            bool fast = true;
+            ld = b[0];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) m[i] = b[i];
+#else
+            const bool fast = class_update4_lane(b, a.eig_floor, m, ld) && !a.force_eigh;
+#endif
+            if (fast) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i) mR[i][k] = m[i];
+                logdetS[k] = ld;
+            } else {
+                atomicOr(&flagS, 1 << k);
+            }
+        }
+#ifdef GSS_EM4_TRACE
+        {
+            EM4_T(c_u1);
+            EM4_ADD(1, c_u1 - c_u0);       // class update of wave 0's lanes
+        }
+#endif
+        __syncthreads();
+        if (update && flagS != 0) {
+            const int flags = flagS;
+            for (int k = wave; k < K; k += 4) {
+                if (!(flags >> k & 1)) continue;
+                // packed upper triangle (row major): diagonals are entries 0, 4, 7, 9 (slots 0-3
+                // of bS), the six others in walk order (re: slots 4-9, im: slots 10-15)
+                cplx vals[COV_SLOTS];
+#pragma unroll
+                for (int s2 = 0; s2 < COV_SLOTS; ++s2) vals[s2] = c_make(0.0, 0.0);
+                int d1 = 0, d2 = 0;
+                if (lane < NE) {
+                    const int p = ts.d12[0];
+                    d1 = p >> 8, d2 = p & 255;
+                    if (d1 == d2) {
+                        vals[0] = c_make(bS[k][d1], 0.0);
+                    } else {
+                        const int off = lane - d1 - 1;          // entries before it minus diagonals
+                        vals[0] = c_make(bS[k][D + off], bS[k][D + 6 + off]);
+                    }
+                }
+                cplx *A = reinterpret_cast<cplx *>(&ldsS[wave][0][0]);
+                class_update_eigh(vals, D, K, a.eig_floor, A, lane, MqS + k, logdetS + k, ts);
+                wave_sync();
+                if (lane < NE) {
+                    const cplx v = MqS[lane * K + k];
+                    if (d1 == d2) {
+                        mR[d1][k] = v.x;
+                    } else {
+                        mR[D + lane - d1 - 1][k] = v.x;
+                        mR[D + 6 + lane - d1 - 1][k] = v.y;
+                    }
                 }
             }
-            tr = wave_sum(tr);
-            cplx *A = reinterpret_cast<cplx *>(scratch[wave]);
-            bool fast = !a.force_eigh && tr > 0.0 && isfinite(tr);
-            if (fast)
-                fast = class_update_chol<1>(vals, D, K, a.eig_floor, A, lane, MqS + k, logdetS + k, ts);
-            if (!fast) {
-                wave_sync();
-                class_update_eigh(vals, D, K, a.eig_floor, A, lane, MqS + k, logdetS + k, ts);
-            }
-            wave_sync();
+            __syncthreads();
         }
-        __syncthreads();
+        constexpr int MODEL = NP * 2 * KP;                 // doubles of the model rows
         if (coop) {
-            // helper 0 hands the model on: B^-1 rows, ln det, pi; the others wait for it
-            double *mS = reinterpret_cast<double *>(MqS);
+            // helper 0 hands the model on: the model rows, ln det, pi; the others wait for it
+            double *mS = &mR[0][0];
             if (update) {
-                if (tid < 2 * NE * K) coop_store(coop_model + tid, mS[tid]);
-                else if (tid < 2 * NE * K + K) coop_store(coop_model + tid, logdetS[tid - 2 * NE * K]);
-                else if (tid < 2 * NE * K + 2 * K) coop_store(coop_model + tid, piS[tid - 2 * NE * K - K]);
+                if (tid < MODEL) coop_store(coop_model + tid, mS[tid]);
+                else if (tid < MODEL + K) coop_store(coop_model + tid, logdetS[tid - MODEL]);
+                else if (tid < MODEL + 2 * K) coop_store(coop_model + tid, piS[tid - MODEL - K]);
                 __syncthreads();
                 if (tid == 0)
                     __hip_atomic_store(coop_flags + 1, it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 if (tid == 0) coop_wait(coop_flags + 1, it + 1);
                 __syncthreads();
-                if (tid < 2 * NE * K) mS[tid] = coop_load(coop_model + tid);
-                else if (tid < 2 * NE * K + K) logdetS[tid - 2 * NE * K] = coop_load(coop_model + tid);
-                else if (tid < 2 * NE * K + 2 * K) piS[tid - 2 * NE * K - K] = coop_load(coop_model + tid);
+                if (tid < MODEL) mS[tid] = coop_load(coop_model + tid);
+                else if (tid < MODEL + K) logdetS[tid - MODEL] = coop_load(coop_model + tid);
+                else if (tid < MODEL + 2 * K) piS[tid - MODEL - K] = coop_load(coop_model + tid);
                 __syncthreads();
             }
         }
-        // B^-1 to this workgroup's copy in global memory, where phase E reads it through the
-        // scalar cache
-        if (tid < NE * K) Mq_rw[tid] = MqS[tid];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the model stores are in L2
-        __syncthreads();
-        __builtin_amdgcn_s_dcache_inv();
-#ifdef GSS_EM4_TRACE
-        {
-            EM4_T(c_g);
-            EM4_ADD(4, c_g - c_f);         // sums + model update
-        }
-#endif
 #ifndef GSS_EM4_LOG_SOFTMAX
         if (tid < K) {
             double ldmin = INFINITY;
             for (int k = 0; k < K; ++k) ldmin = fmin(ldmin, logdetS[k]);
             cS[tid] = piS[tid] * exp(ldmin - logdetS[tid]);
         }
+#endif
         __syncthreads();
+#ifdef GSS_EM4_TRACE
+        {
+            EM4_T(c_g);
+            EM4_ADD(4, c_g - c_f);         // sums + model update
+        }
 #endif
     }
 #ifdef GSS_EM4_TRACE
     {
         EM4_T(c_end);
         EM4_ADD(5, c_end - c_start);
+        if (tid == 0 && blockIdx.x < 1024)
+            for (int i = 0; i < 6; ++i) g_em4_phase[blockIdx.x * 6 + i] = em4_acc[i];
     }
 #endif
 }
@@ -1616,7 +1808,7 @@ size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K) {
     b += align_up(sizeof(int) * 2 * NE);                         // tri_tab
     b += align_up(sizeof(cplx) * (size_t)F * D * T);             // Yn (register-form E-step)
     b += align_up(sizeof(double) * (size_t)F * ((T + 63) / 64 + 4) * K);
-    b += 2 * align_up(16 * (2 + 16 * (K * 17) + 2 * NE * K + 2 * K + 8 + 16 * NE * K));   // em_onchip coop
+    b += 2 * align_up(16 * (2 + 16 * (K * 17) + 16 * (K + 1) + 2 * K + 8 + 16 * NE * K));   // em_onchip coop
     return b + 4096;
 }
 
@@ -1736,7 +1928,7 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
         if (coop_g == 1) coop_g = 0;
         if (coop_g > 0) {
             o.coop_g = coop_g;
-            o.coop = arena_alloc_t<double>(ctx, 2 + (size_t)coop_g * (K * 16 + K) + 2 * NE * K + 2 * K + 8);
+            o.coop = arena_alloc_t<double>(ctx, 2 + (size_t)coop_g * (K * 16 + K) + 16 * (K + 1) + 2 * K + 8);
             o.Mq_coop = arena_alloc_t<cplx>(ctx, (size_t)coop_g * NE * K);
             GSS_REQUIRE(ctx, o.coop && o.Mq_coop, GSS_ERR_NOMEM, "cacgmm workspace");
         }

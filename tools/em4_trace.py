@@ -32,8 +32,19 @@ ctx.synchronize()
 buf = np.zeros((1024, 6), dtype=np.int64)
 assert lib.gss_debug_em4_phase(buf.ctypes.data_as(ctypes.c_void_p), 1024) == 0
 b = buf[buf[:, 5] > 0].astype(float)
-names = ['phase E', 'barrier 1', 'LDS stores + barrier 2', 'phase M', 'sums + model update', 'whole kernel']
+names = ['phase E', 'class update (lanes of wave 0; part of sums + model update)', 'LDS stores', 'phase M', 'sums + model update', 'whole kernel']
 print(f'{len(b)} workgroups, T = {res.T}; mean shader cycles of wave 0 (share of the kernel):')
 for i, nme in enumerate(names):
-    print(f'  {nme:24s} {b[:, i].mean():12.0f}  {b[:, i].mean() / b[:, 5].mean():6.3f}')
+    print(f'  {nme:64s} {b[:, i].mean():12.0f}  {b[:, i].mean() / b[:, 5].mean():6.3f}')
 print(f'  kernel cycles min / max over workgroups: {b[:, 5].min():.0f} / {b[:, 5].max():.0f}')
+w = buf[:, 5].astype(float)
+idx = np.nonzero(w > 0)[0]
+q = np.percentile(w[idx], [0, 5, 25, 50, 75, 95, 100])
+print('  whole-kernel cycles percentiles 0/5/25/50/75/95/100:', ' '.join(f'{x:.0f}' for x in q))
+slow = idx[np.argsort(-w[idx])[:24]]
+print('  slowest workgroups (blockIdx: cycles):', ' '.join(f'{i}:{w[i]:.0f}' for i in slow))
+fast = idx[np.argsort(w[idx])[:12]]
+print('  fastest workgroups:', ' '.join(f'{i}:{w[i]:.0f}' for i in fast))
+for lo in range(0, 520, 64):
+    sel = idx[(idx >= lo) & (idx < lo + 64)]
+    print(f'  blockIdx {lo:3d}-{lo + 63:3d}: mean {w[sel].mean():.0f}  E {buf[sel, 0].mean():.0f}  M {buf[sel, 3].mean():.0f}  model {buf[sel, 4].mean():.0f}')
