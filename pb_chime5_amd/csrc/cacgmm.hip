@@ -309,40 +309,109 @@ __global__ __launch_bounds__(256) void em_estep_reg_kernel(EmArgs a, const cplx 
                 for (int k = 0; k < K; ++k) ring[(e + P) % RING][k] = Mf[(e + P) * K + k];
             }
             const double pr = y[d1].x * y[d2].x + y[d1].y * y[d2].y;
-            const double pim = y[d1].y * y[d2].x - y[d1].x * y[d2].y;   // 0 on the diagonal
+            if (d1 == d2) {
+                // (the imaginary parts of a diagonal entry and of its product are zero: skipping
+                // them changes no bit of q)
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const cplx m = ring[e % RING][k];
-                q[k] = fma(m.x, pr, q[k]);
-                q[k] = fma(m.y, pim, q[k]);
+                for (int k = 0; k < K; ++k) q[k] = fma(ring[e % RING][k].x, pr, q[k]);
+            } else {
+                const double pim = y[d1].y * y[d2].x - y[d1].x * y[d2].y;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const cplx m = ring[e % RING][k];
+                    q[k] = fma(m.x, pr, q[k]);
+                    q[k] = fma(m.y, pim, q[k]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             ++e;
         }
     }
-    double lp[K], mx = -INFINITY;
+    // Posterior  pi_k exp(-D ln q_k - ln det_k) / sum  without a logarithm per frame: relative
+    // to the class with the smallest q it is  (q_min / q_k)^D c_k  with
+    // c_k = pi_k exp(ln det_min - ln det_k)  -- the common factor cancels in the normalisation.
+    // c_k is one exponential per class and WAVE (lane k computes it, an SGPR pair hands it to
+    // all lanes) instead of K logarithms and K exponentials per FRAME: the transcendental
+    // functions were 600 of the kernel's 5200 instructions per wave, and the integer power is
+    // the more accurate form (24 roundings against the 1e-13 of exp(500 +- ...)).  One
+    // reciprocal per class serves the ratio and the M-step weight gamma / q, one more the
+    // normalisation.  A frame whose terms all underflow (sum < 1e-280: the classes' ln det
+    // hundreds apart AND the q ratios against them) takes the log form below, which is also
+    // the form of em_estep_kernel.
+    // (The walk sits at the 128 registers of four waves per SIMD and at the SGPR limit, and
+    // nothing orders the epilogue's loads after it: activity bytes, ln det, pi -- or the lane
+    // masks made of them -- were moved above the walk and spilled its ring of model rows lane
+    // by lane (5 x slower).  So their addresses depend on the walk's result: `dep` is 0
+    // unless q is NaN.)
+    const int dep = q[0] != q[0] ? 1 : 0;
+    const int tcl = (int)tc - dep;
+    auto lane_bcast = [](double x, int k) {
+        const unsigned long long u = __double_as_longlong(x);
+        const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, k);
+        const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), k);
+        return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+    };
+    double cls, ldl, pil;
+    {
+        const int kk = (lane < K ? lane : K - 1) - (lane > 0 ? dep : 0);
+        ldl = a.logdet[f * K + kk];
+        pil = a.pi[f * K + kk];
+        double ldmin = INFINITY;
+#pragma unroll
+        for (int k = 0; k < K; ++k) ldmin = fmin(ldmin, lane_bcast(ldl, k));
+        cls = pil * exp(ldmin - ldl);
+    }
+    double qmin = INFINITY;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         q[k] = fmax(fabs(q[k]), GSS_TINY);
-        lp[k] = -(double)D * log(q[k]) - a.logdet[f * K + k];
-        mx = fmax(mx, lp[k]);
+        qmin = fmin(qmin, q[k]);
     }
-    double v[K], ssum = 0.0;
+    uint8_t act[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) act[k] = a.act[(int64_t)k * a.act_stride + (tcl < 0 ? 0 : tcl)];
+    double v[K], iq[K], ssum = 0.0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        v[k] = exp(lp[k] - mx) * a.pi[f * K + k];
-        if (a.masked) v[k] *= (valid && a.act[(int64_t)k * a.act_stride + tc]) ? 1.0 : 0.0;
+        iq[k] = 1.0 / q[k];
+        const double r = qmin * iq[k];
+        double p = 1.0, b = r;            // r^D by squaring (D is a template parameter)
+#pragma unroll
+        for (int bit = D; bit > 0; bit >>= 1) {
+            if (bit & 1) p = p * b;
+            b = b * b;
+        }
+        v[k] = p * lane_bcast(cls, k);
+        v[k] = (!a.masked || (valid && act[k])) ? v[k] : 0.0;
         ssum += v[k];
     }
-    ssum = fmax(ssum, GSS_TINY);
+    if (ssum < 1e-280) {
+        double lp[K], mx = -INFINITY;
+        ssum = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            lp[k] = -(double)D * log(q[k]) - lane_bcast(ldl, k);
+            mx = fmax(mx, lp[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            v[k] = exp(lp[k] - mx) * lane_bcast(pil, k);
+            v[k] = (!a.masked || (valid && act[k])) ? v[k] : 0.0;
+            ssum += v[k];
+        }
+    }
+    const double is = 1.0 / fmax(ssum, GSS_TINY);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        double gam = v[k] / ssum;
+        double gam = v[k] * is;
         if (a.aff_eps != 0.0) gam = fmin(fmax(gam, a.aff_eps), 1.0 - a.aff_eps);
         if (MODE == MODE_PREDICT) {
             if (valid) a.gamma[((int64_t)f * K + k) * T + t] = gam;
         } else {
-            if (valid) a.W[((int64_t)f * K + k) * T + t] = gam / fmax(q[k], 10.0 * GSS_TINY);
+            // gamma / max(q, 10 tiny)
+            if (valid)
+                a.W[((int64_t)f * K + k) * T + t] =
+                    gam * (q[k] < 10.0 * GSS_TINY ? 1.0 / (10.0 * GSS_TINY) : iq[k]);
             const double tot = wave_sum(valid ? gam : 0.0);
             if (lane == 0) a.Sg[(((int64_t)f * ntile + tile) * wpb + wave) * K + k] = tot;
         }

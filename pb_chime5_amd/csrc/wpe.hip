@@ -1998,6 +1998,12 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         }
         {
             const int nblk = (n + CH_NB - 1) / CH_NB;
+            // GSS_PROF_DETAIL=1: one profile row per block column (tools/wpe_kprof.py)
+            static const bool detail = getenv("GSS_PROF_DETAIL") != nullptr;
+            static const char *trsm_names[] = {"wpe_chol_trsm_J0", "wpe_chol_trsm_J1", "wpe_chol_trsm_J2",
+                                               "wpe_chol_trsm_J3", "wpe_chol_trsm_J4", "wpe_chol_trsm_J5+"};
+            static const char *upd_names[] = {"wpe_chol_update_J0", "wpe_chol_update_J1", "wpe_chol_update_J2",
+                                              "wpe_chol_update_J3", "wpe_chol_update_J4", "wpe_chol_update_J5+"};
             for (int J = 0; J < nblk; ++J) {
                 const int j0 = J * CH_NB, nb = std::min(CH_NB, n - j0);
                 // (blocks J > 0 are factored by group 0 of the preceding trailing update)
@@ -2008,7 +2014,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                     GSS_LAUNCH_CHECK(ctx, "chol_diag_kernel");
                 }
                 {
-                    GSS_PROF(ctx, "wpe_chol_trsm");
+                    GSS_PROF(ctx, detail ? trsm_names[std::min(J, 5)] : "wpe_chol_trsm");
                     const int npanel = (n - j0 - nb + 15) / 16 + (D + 15) / 16;
                     hipLaunchKernelGGL(chol_trsm_kernel, dim3(xcd_grid((npanel + 3) / 4, F)),
                                        dim3(256), panel_lds, ctx->stream, R, P, F, n, D, j0);
@@ -2016,7 +2022,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                 }
                 const int nupd = upd_count[J];
                 if (nupd > 0) {
-                    GSS_PROF(ctx, "wpe_chol_update");
+                    GSS_PROF(ctx, detail ? upd_names[std::min(J, 5)] : "wpe_chol_update");
                     const int ndiag = upd_ndiag[J];
                     const dim3 g((ndiag > 0 ? (F + 7) / 8 * 8 : 0) +
                                  xcd_grid((nupd - ndiag + UPD_WAVES - 1) / UPD_WAVES, F)), b(64 * UPD_WAVES);
