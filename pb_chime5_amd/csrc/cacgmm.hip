@@ -33,6 +33,44 @@ constexpr int EM_TS = EM_TILE + 1;   // padded LDS row stride (complex elements)
 
 enum { MODE_FIRST = 0, MODE_EM = 1, MODE_PREDICT = 2 };
 
+// Wave priority that falls with the progress of a workgroup (quarters of its work done: 3, 2,
+// 1, 0).  For launches whose workgroups are all resident from the start and should END
+// together: the issue arbiter serves the oldest wave first, so the co-resident workgroups of a
+// CU otherwise finish one after the other and the tail of the launch runs at a fraction of
+// the occupancy; with this whoever is ahead waits for the others.
+__device__ __forceinline__ void set_progress_priority(int done, int total) {
+    const int q4 = 4 * done / total;
+    if (q4 <= 0) __builtin_amdgcn_s_setprio(3);
+    else if (q4 == 1) __builtin_amdgcn_s_setprio(2);
+    else if (q4 == 2) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
+// Static balanced partition of the M-step (D > 12): the (frequency, 64-frame tile) items of an
+// utterance, frequency major, are cut into S equal runs, one per RESIDENT workgroup (S = what
+// the chip holds at once), instead of F x nch workgroups of nch equal chunks per frequency:
+// every workgroup starts at t = 0 and ends with the others (the chunked launch drained for
+// the last fifth of its span at falling residency: tools/wcov_trace.py), and a frequency is
+// cut into 2 - 3 segments instead of 5 - 6, so the fixed cost of a segment (cross-group
+// reduction, scattered store of the partial sums: 12 - 23 % of a workgroup's life) and the
+// partial sums em_chol re-reads halve.  Segment j of frequency f (its j-th run) writes
+// part[(f * maxseg + j) ...]; S = 0: the chunked form.  The partition depends on (F, T, S)
+// only -- the same summation order on every run on the same chip.
+struct MsegPlan {
+    int S, ntile, base, rem, maxseg;
+};
+__host__ __device__ __forceinline__ int mseg_begin(const MsegPlan &p, int slot) {
+    return slot * p.base + (slot < p.rem ? slot : p.rem);
+}
+__host__ __device__ __forceinline__ int mseg_slot_of(const MsegPlan &p, int item) {
+    const int head = p.rem * (p.base + 1);
+    return item < head ? item / (p.base + 1) : p.rem + (item - head) / p.base;
+}
+// number of segments (partial sums) of frequency f
+__host__ __device__ __forceinline__ int mseg_count(const MsegPlan &p, int f) {
+    return mseg_slot_of(p, f * p.ntile + p.ntile - 1) - mseg_slot_of(p, f * p.ntile) + 1;
+}
+
 struct EmArgs {
     const cplx *Y;          // (F,T,D)
     const uint8_t *act;     // (K,act_stride), first T columns used
@@ -47,6 +85,7 @@ struct EmArgs {
     int F, D, NE, nch, chunk_frames;
     int masked;             // multiply the activity mask into the posteriors
     double aff_eps;         // clip, 0 = none
+    MsegPlan mseg;          // M-step partition (S = 0: nch chunks per frequency)
 };
 
 // Load frames [t0, t0+64) of one frequency into LDS as ys[d][tl], optionally unit
@@ -456,6 +495,18 @@ __host__ __device__ inline WcovLds wcov_lds_layout(int D, int KW) {
     return L;
 }
 
+#ifdef GSS_WCOV_TRACE
+// tools/wcov_trace.py: per workgroup (wave 0): start, end (100 MHz clock) and shader cycles in
+// staging (loads + LDS stores + barriers), accumulation, final reduction + store
+__device__ long long g_wcov_phase[8192 * 6];
+extern "C" int gss_debug_wcov_phase(long long *host, int entries) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wcov_phase), sizeof(long long) * 6 * entries);
+}
+#define WCOV_T(var) const long long var = __builtin_readcyclecounter()
+#else
+#define WCOV_T(var)
+#endif
+
 // KW weight rows per launch out of the Ktot rows of W / part, starting at row k0 (the
 // M-step of more than 8 classes runs in groups).
 template <int KW, bool NORMALISE, bool SRC_FDT, bool PREFETCH = false>
@@ -463,7 +514,7 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
                                                    const double *__restrict__ W, int F,
                                                    int64_t T, int D, int NE, int nch,
                                                    int chunk_frames, cplx *__restrict__ part,
-                                                   int Ktot, int k0) {
+                                                   int Ktot, int k0, MsegPlan plan) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WcovLds L = wcov_lds_layout(D, KW);
     const int Dp = L.Dp;
@@ -472,14 +523,28 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
     double *scratch = reinterpret_cast<double *>(smem + L.scratch);
     unsigned char *blk = reinterpret_cast<unsigned char *>(smem + L.blk);
 
-    int f, chunk;
-    if (!xcd_group_map(nch, F, f, chunk)) return;
+    // chunked form: ONE segment (f, chunk); static partition: the run of items of this slot,
+    // one segment per frequency it touches
+    int f = 0, chunk = 0, item = 0, item_end = 1;
+    if (plan.S > 0) {
+        item = mseg_begin(plan, blockIdx.x);
+        item_end = mseg_begin(plan, blockIdx.x + 1);
+    }
+    const int item_begin = item;
+    if (plan.S > 0) {
+    } else if (!xcd_group_map(nch, F, f, chunk)) {
+        return;
+    }
     const int tid = threadIdx.x;
     const int tl = tid & 63, g = tid >> 6;
-    const int64_t c0 = (int64_t)chunk * chunk_frames;
-    const int64_t c1 = c0 + chunk_frames < T ? c0 + chunk_frames : T;
-    const cplx *Yf = Y + (int64_t)f * T * D;
-    const double *Wf = W + ((int64_t)f * Ktot + k0) * T;
+#ifdef GSS_WCOV_TRACE
+    long long tr_stage = 0, tr_acc = 0;
+    const long long tr_wall0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    WCOV_T(tr_c0);
+#ifdef GSS_WCOV_TRACE
+    long long tr_red = 0;
+#endif
 
     {
         const int nb2 = Dp / 2;
@@ -491,11 +556,32 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
             }
         }
     }
-    if (Dp != D)
-        for (int j = tid; j < EM_TS; j += blockDim.x) ys[D * EM_TS + j] = c_make(0.0, 0.0);
-
     const int mb = tid % L.nblk, fg = tid / L.nblk;
     const bool m_active = fg < L.nfg;
+  for (bool first_seg = true; item < item_end; first_seg = false) {
+    if (Dp != D) {
+        // (the padding row shares LDS with the reduction of the previous segment)
+        if (!first_seg) __syncthreads();
+        for (int j = tid; j < EM_TS; j += blockDim.x) ys[D * EM_TS + j] = c_make(0.0, 0.0);
+    }
+    int64_t c0, c1;
+    int nch_f = nch;
+    if (plan.S > 0) {
+        f = item / plan.ntile;
+        const int tile0 = item - f * plan.ntile;
+        const int ntl = min(plan.ntile - tile0, item_end - item);
+        c0 = (int64_t)tile0 * EM_TILE;
+        c1 = min(T, (int64_t)(tile0 + ntl) * EM_TILE);
+        chunk = (int)blockIdx.x - mseg_slot_of(plan, f * plan.ntile);
+        nch_f = plan.maxseg;
+        item += ntl;
+    } else {
+        c0 = (int64_t)chunk * chunk_frames;
+        c1 = c0 + chunk_frames < T ? c0 + chunk_frames : T;
+        item = item_end;
+    }
+    const cplx *Yf = Y + (int64_t)f * T * D;
+    const double *Wf = W + ((int64_t)f * Ktot + k0) * T;
     cplx acc[4][KW];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -524,6 +610,15 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
     };
     if (SRC_FDT && PREFETCH) prefetch(c0);
     for (int64_t t0 = c0; t0 < c1; t0 += EM_TILE) {
+        WCOV_T(tr_a);
+        if (plan.S > 0) {
+            // Static partition: the workgroups of a CU must END together (nothing refills a
+            // free slot), but the issue arbiter serves the oldest first -- they finished one
+            // after the other and the last third of the work ran with one wave per SIMD
+            // (tools/wcov_trace.py).  Priority falls with progress: whoever is ahead waits.
+            set_progress_priority(item - (int)((c1 - t0 + EM_TILE - 1) / EM_TILE) - item_begin,
+                                  item_end - item_begin);
+        }
         __syncthreads();
         if (SRC_FDT) {
             // Y is already the (F, D, T) unit-normalised copy: rows are contiguous.  Without
@@ -550,6 +645,7 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
             }
             __syncthreads();
         }
+        WCOV_T(tr_b);
         if (m_active) {
             const int nfr = (int)min((int64_t)EM_TILE, c1 - t0);
             const int bi = blk[2 * mb], bj = blk[2 * mb + 1];
@@ -573,7 +669,15 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
                 }
             }
         }
+#ifdef GSS_WCOV_TRACE
+        {
+            WCOV_T(tr_c);
+            tr_stage += tr_b - tr_a;
+            tr_acc += tr_c - tr_b;
+        }
+#endif
     }
+    WCOV_T(tr_c1);
     // reduce the frame groups (groups fg > 0 -> LDS -> group 0, red_groups per round, always
     // added in ascending group order), then store
     cplx *red = reinterpret_cast<cplx *>(smem + L.ys);
@@ -600,7 +704,7 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
         }
     }
     if (fg == 0) {
-        cplx *pp = part + (((int64_t)f * nch + chunk) * Ktot + k0) * NE;
+        cplx *pp = part + (((int64_t)f * nch_f + chunk) * Ktot + k0) * NE;
         const int bi = blk[2 * mb], bj = blk[2 * mb + 1];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -612,6 +716,27 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
             }
         }
     }
+#ifdef GSS_WCOV_TRACE
+    {
+        WCOV_T(tr_c2s);
+        tr_red += tr_c2s - tr_c1;
+    }
+#endif
+  }   // segments
+#ifdef GSS_WCOV_TRACE
+    {
+        WCOV_T(tr_c2);
+        if (tid == 0 && blockIdx.x < 8192) {
+            long long *o = g_wcov_phase + 6 * blockIdx.x;
+            o[0] = tr_wall0;
+            o[1] = __builtin_amdgcn_s_memrealtime();
+            o[2] = tr_stage;
+            o[3] = tr_acc;
+            o[4] = tr_red;
+            o[5] = tr_c2 - tr_c0;
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ M-step, register form
@@ -769,8 +894,9 @@ __device__ inline double sum_gamma(const double *__restrict__ Sg, int sg_nch, in
 constexpr int COV_SLOTS = 9;
 static_assert(COV_SLOTS == sizeof(TriSlots::d12) / sizeof(int), "TriSlots");
 
+// (nch: partial-sum records per frequency in the layout, cnt <= nch: how many of them hold sums)
 template <int NS = COV_SLOTS>
-__device__ inline double reduce_covariance(const cplx *__restrict__ Bp, int nch, int D, int K,
+__device__ inline double reduce_covariance(const cplx *__restrict__ Bp, int nch, int cnt, int D, int K,
                                            int k, int f, double den, cplx (&vals)[COV_SLOTS],
                                            int lane, const TriSlots &ts) {
     const int NE = tri_count(D);
@@ -782,13 +908,13 @@ __device__ inline double reduce_covariance(const cplx *__restrict__ Bp, int nch,
 #pragma unroll
     for (int s = 0; s < COV_SLOTS; ++s) vals[s] = c_make(0.0, 0.0);
     const cplx *src = Bp + ((int64_t)f * nch * K + k) * NE + lane;
-    for (int c = 0; c < nch; c += CB) {
+    for (int c = 0; c < cnt; c += CB) {
         cplx t[NS][CB];
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int j = 0; j < CB; ++j)
-                t[s][j] = (lane + 64 * s < NE && c + j < nch) ? src[(int64_t)(c + j) * K * NE + 64 * s]
+                t[s][j] = (lane + 64 * s < NE && c + j < cnt) ? src[(int64_t)(c + j) * K * NE + 64 * s]
                                                               : c_make(0.0, 0.0);
 #pragma unroll
         for (int s = 0; s < NS; ++s)
@@ -1004,11 +1130,13 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
                                                      double *__restrict__ logdet,
                                                      double *__restrict__ pi,
                                                      int *__restrict__ need_eigh,
-                                                     const int *__restrict__ tri_tab) {
+                                                     const int *__restrict__ tri_tab,
+                                                     MsegPlan plan) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NE = tri_count(D);
     cplx *A = reinterpret_cast<cplx *>(smem);                  // D * (8 NR + 1) + D doubles
     const int k = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    const int cnt = plan.S > 0 ? mseg_count(plan, f) : nch;
 
     CHOL_STAMP(0);
     const TriSlots ts = tri_slots_tab(tri_tab, NE, lane);
@@ -1018,7 +1146,7 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
     CHOL_STAMP(1);
     CHOL_STAMP(2);
     cplx vals[COV_SLOTS];
-    const double tr = reduce_covariance<cov_slots_for(NR)>(Bp, nch, D, K, k, f, den, vals, lane, ts);
+    const double tr = reduce_covariance<cov_slots_for(NR)>(Bp, nch, cnt, D, K, k, f, den, vals, lane, ts);
     CHOL_STAMP(3);
     bool fast = !force_eigh && tr > 0.0 && isfinite(tr);
     if (fast)
@@ -1036,16 +1164,18 @@ __global__ __launch_bounds__(64) void em_eigh_kernel(const cplx *__restrict__ Bp
                                                      const int *__restrict__ need_eigh,
                                                      cplx *__restrict__ Mq,
                                                      double *__restrict__ logdet,
-                                                     const int *__restrict__ tri_tab) {
+                                                     const int *__restrict__ tri_tab,
+                                                     MsegPlan plan) {
     const int k = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
     if (!need_eigh[f * K + k]) return;
+    const int cnt = plan.S > 0 ? mseg_count(plan, f) : nch;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NE = tri_count(D);
     const double sg = sum_gamma(Sg, sg_nch, K, k, f, lane);
     const double den = fmax(sg, GSS_TINY);
     const TriSlots ts = tri_slots_tab(tri_tab, NE, lane);
     cplx vals[COV_SLOTS];
-    reduce_covariance(Bp, nch, D, K, k, f, den, vals, lane, ts);
+    reduce_covariance(Bp, nch, cnt, D, K, k, f, den, vals, lane, ts);
     class_update_eigh(vals, D, K, eig_floor, reinterpret_cast<cplx *>(smem), lane,
                       Mq + (int64_t)f * NE * K + k, logdet + f * K + k, ts);
 }
@@ -1080,6 +1210,9 @@ __device__ __forceinline__ double row16_sum(double v) {      // total in lane 15
 
 constexpr int OC_FRAMES = 256;
 
+#ifndef GSS_EM4_PRIO
+#define GSS_EM4_PRIO 1
+#endif
 #ifndef GSS_EM4_ABL
 #define GSS_EM4_ABL 0      // timing-only ablations of em_onchip4_kernel (wrong results)
 #endif
@@ -1284,6 +1417,8 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
         const bool predict = it == n_fit;
         const bool masked = predict ? a.iterations_post == 0 : it < a.iterations;
         const double aff_eps = predict ? 0.0 : 1e-10;
+        // (the two workgroups of a CU end together: the older one ran 19 % ahead)
+        if (GSS_EM4_PRIO) set_progress_priority(it, n_fit + 1);
         double acc[K], sg[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) acc[k] = sg[k] = 0.0;
@@ -1775,6 +1910,25 @@ int launch_estep_reg_k(gss_ctx *ctx, int K, int mode, const EmArgs &a, const cpl
     return gss_fail(ctx, GSS_ERR_UNSUPPORTED, "cacgmm: K=%d", K);
 }
 
+// Resident workgroups of the M-step kernel on this device (static partition: one run of
+// items each).
+template <int KW>
+int mstep_resident_slots(gss_ctx *ctx, int D, int *slots) {
+    const size_t lds = wcov_lds_layout(D, KW).total;
+    GSS_TRY(raise_lds_limit(ctx, wcov_kernel<KW, false, true>, lds));
+    int per_cu = 0, cus = 0;
+    GSS_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                           &per_cu, reinterpret_cast<const void *>(wcov_kernel<KW, false, true>), 256, lds));
+    GSS_HIP_CHECK(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    *slots = std::max(per_cu, 1) * cus;
+    return GSS_OK;
+}
+// (pf_max_d: up to here the tiled M-step prefetches across tiles and keeps the chunked form)
+static int mstep_prefetch_max_d() {
+    static const int v = getenv("GSS_MSTEP_PREFETCH_D") ? atoi(getenv("GSS_MSTEP_PREFETCH_D")) : 12;
+    return v;
+}
+
 template <int KW>
 int launch_mstep(gss_ctx *ctx, const EmArgs &a, const cplx *Yn, int F, int K, int k0) {
     const size_t lds = wcov_lds_layout(a.D, KW).total;
@@ -1790,24 +1944,25 @@ int launch_mstep(gss_ctx *ctx, const EmArgs &a, const cplx *Yn, int F, int K, in
         // (cross-tile prefetch against loading the tile in place, ms per launch at T = 2169:
         // D = 10 0.113 / 0.120, D = 12 0.122 / 0.124, D = 20 0.219 / 0.207; D = 24, T = 941:
         // 0.130 / 0.118)
-        static const int pf_max_d = getenv("GSS_MSTEP_PREFETCH_D") ? atoi(getenv("GSS_MSTEP_PREFETCH_D")) : 12;
-        if (a.D <= pf_max_d) {
+        if (a.D <= mstep_prefetch_max_d()) {
             GSS_TRY(raise_lds_limit(ctx, wcov_kernel<KW, false, true, true>, lds));
             hipLaunchKernelGGL((wcov_kernel<KW, false, true, true>), dim3(xcd_grid(a.nch, F)),
                                dim3(256), lds, ctx->stream, Yn, a.W, F, a.T, a.D, a.NE, a.nch,
-                               a.chunk_frames, a.Bp, K, k0);
+                               a.chunk_frames, a.Bp, K, k0, MsegPlan{});
         } else {
             GSS_TRY(raise_lds_limit(ctx, wcov_kernel<KW, false, true>, lds));
-            hipLaunchKernelGGL((wcov_kernel<KW, false, true>), dim3(xcd_grid(a.nch, F)), dim3(256),
+            const dim3 grid(a.mseg.S > 0 ? a.mseg.S : xcd_grid(a.nch, F));
+            hipLaunchKernelGGL((wcov_kernel<KW, false, true>), grid, dim3(256),
                                lds, ctx->stream, Yn, a.W, F, a.T, a.D, a.NE, a.nch, a.chunk_frames,
-                               a.Bp, K, k0);
+                               a.Bp, K, k0, a.mseg);
         }
         GSS_LAUNCH_CHECK(ctx, "wcov_kernel");
         return GSS_OK;
     }
     GSS_TRY(raise_lds_limit(ctx, wcov_kernel<KW, true, false>, lds));
     hipLaunchKernelGGL((wcov_kernel<KW, true, false>), dim3(xcd_grid(a.nch, F)), dim3(256), lds,
-                       ctx->stream, a.Y, a.W, F, a.T, a.D, a.NE, a.nch, a.chunk_frames, a.Bp, K, k0);
+                       ctx->stream, a.Y, a.W, F, a.T, a.D, a.NE, a.nch, a.chunk_frames, a.Bp, K, k0,
+                       MsegPlan{});
     GSS_LAUNCH_CHECK(ctx, "wcov_kernel");
     return GSS_OK;
 }
@@ -1849,6 +2004,34 @@ int launch_mstep_k(gss_ctx *ctx, int K, const EmArgs &a, const cplx *Yn, int F) 
     return GSS_OK;
 }
 
+int mstep_resident_slots_k(gss_ctx *ctx, int KW, int D, int *slots) {
+    GSS_K_SWITCH8(KW, mstep_resident_slots<KK>(ctx, D, slots));
+    return gss_fail(ctx, GSS_ERR_UNSUPPORTED, "cacgmm: KW=%d", KW);
+}
+
+// The M-step's static partition for (F, T) on this device; S = 0 where the chunked form stays
+// (one array, the prefetching form of few channels, GSS_MSTEP_CHUNKED=1).
+int mstep_plan(gss_ctx *ctx, int F, int64_t T, int D, int K, MsegPlan *plan) {
+    *plan = MsegPlan{};
+    if (D <= mstep_prefetch_max_d() || getenv("GSS_MSTEP_CHUNKED") != nullptr) return GSS_OK;
+    const int ngroups = (K + 7) / 8, per = (K + ngroups - 1) / ngroups;
+    int slots = 0;
+    GSS_TRY(mstep_resident_slots_k(ctx, per, D, &slots));
+    if (const char *e = getenv("GSS_MSTEP_SLOTS")) slots = std::max(1, atoi(e));
+    const int64_t ntile = (T + EM_TILE - 1) / EM_TILE, N = ntile * F;
+    if (N >= (1LL << 30) || ntile < 1) return GSS_OK;
+    plan->ntile = (int)ntile;
+    plan->S = (int)std::min<int64_t>(slots, N);
+    plan->base = (int)(N / plan->S);
+    plan->rem = (int)(N % plan->S);
+    for (int f = 0; f < F; ++f) plan->maxseg = std::max(plan->maxseg, mseg_count(*plan, f));
+    // (few frequencies on a large chip: a run is a tile or two and a frequency would be cut
+    // into more segments than chunks -- the chunked form stays; the workspace holds 8 records)
+    if (plan->maxseg > 8) *plan = MsegPlan{};
+    return GSS_OK;
+}
+
+
 }  // namespace
 
 // PSD accumulation of the beamformer: same kernel, raw observations, two masks.
@@ -1858,7 +2041,8 @@ int psd_partials_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const
     const size_t lds = wcov_lds_layout(D, 2).total;
     GSS_TRY(raise_lds_limit(ctx, wcov_kernel<2, false, false>, lds));
     hipLaunchKernelGGL((wcov_kernel<2, false, false>), dim3(xcd_grid(nch, F)), dim3(256), lds,
-                       ctx->stream, Y, W2, F, T, D, tri_count(D), nch, chunk_frames, part, 2, 0);
+                       ctx->stream, Y, W2, F, T, D, tri_count(D), nch, chunk_frames, part, 2, 0,
+                       MsegPlan{});
     GSS_LAUNCH_CHECK(ctx, "wcov_kernel");
     return GSS_OK;
 }
@@ -1871,7 +2055,7 @@ size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K) {
     b += align_up(sizeof(cplx) * (size_t)F * NE * K);            // Mq
     b += 2 * align_up(sizeof(double) * (size_t)F * K);           // logdet, pi
     b += align_up(sizeof(double) * (size_t)F * K * T);           // W
-    b += align_up(sizeof(cplx) * (size_t)F * nch * K * NE);      // Bp
+    b += align_up(sizeof(cplx) * (size_t)F * std::max(nch, 8) * K * NE);   // Bp (chunks, or <= 8 segments)
     b += align_up(sizeof(double) * (size_t)F * nch * K);         // Sg
     b += align_up(sizeof(int) * (size_t)F * K);                  // need_eigh
     b += align_up(sizeof(int) * 2 * NE);                         // tri_tab
@@ -1893,11 +2077,14 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     a.D = D;
     a.NE = NE;
     a.nch = em_chunks(F, T, D, &a.chunk_frames);
+    GSS_TRY(mstep_plan(ctx, F, T, D, K, &a.mseg));
+    // partial-sum records per frequency: chunks, or segments of the static partition
+    const int bp_nch = a.mseg.S > 0 ? a.mseg.maxseg : a.nch;
     cplx *Mq = arena_alloc_t<cplx>(ctx, (size_t)F * NE * K);
     double *logdet = arena_alloc_t<double>(ctx, (size_t)F * K);
     double *pi = arena_alloc_t<double>(ctx, (size_t)F * K);
     a.W = arena_alloc_t<double>(ctx, (size_t)F * K * T);
-    a.Bp = arena_alloc_t<cplx>(ctx, (size_t)F * a.nch * K * NE);
+    a.Bp = arena_alloc_t<cplx>(ctx, (size_t)F * bp_nch * K * NE);
     a.Sg = arena_alloc_t<double>(ctx, (size_t)F * a.nch * K);
     GSS_REQUIRE(ctx, Mq && logdet && pi && a.W && a.Bp && a.Sg, GSS_ERR_NOMEM,
                 "cacgmm workspace");
@@ -1962,14 +2149,15 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
             const size_t lds = sizeof(cplx) * (size_t)D * (8 * nr + 1) + sizeof(double) * D;
             auto kern = nr <= 1 ? em_chol_kernel<1> : nr == 2 ? em_chol_kernel<2>
                         : nr == 3 ? em_chol_kernel<3> : em_chol_kernel<4>;
-            hipLaunchKernelGGL(kern, dim3(K, F), dim3(64), lds, ctx->stream, a.Bp, a.Sg, a.nch,
-                               sg_nch, D, K, T, 1e-10, force_eigh, Mq, logdet, pi, need_eigh, tri_tab);
+            hipLaunchKernelGGL(kern, dim3(K, F), dim3(64), lds, ctx->stream, a.Bp, a.Sg, bp_nch,
+                               sg_nch, D, K, T, 1e-10, force_eigh, Mq, logdet, pi, need_eigh, tri_tab,
+                               a.mseg);
             GSS_LAUNCH_CHECK(ctx, "em_chol_kernel");
         }
         {
             GSS_PROF(ctx, "em_eigh");
             hipLaunchKernelGGL(em_eigh_kernel, dim3(K, F), dim3(64), eigh_lds, ctx->stream, a.Bp,
-                               a.Sg, a.nch, sg_nch, D, K, 1e-10, need_eigh, Mq, logdet, tri_tab);
+                               a.Sg, bp_nch, sg_nch, D, K, 1e-10, need_eigh, Mq, logdet, tri_tab, a.mseg);
             GSS_LAUNCH_CHECK(ctx, "em_eigh_kernel");
         }
         return GSS_OK;
