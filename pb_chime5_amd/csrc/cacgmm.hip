@@ -28,6 +28,12 @@
 
 namespace {
 
+#ifndef GSS_CHOL_PRIO
+#define GSS_CHOL_PRIO 1       // the same in em_chol (loads 3, sweep 2, product 0): -2 %
+#endif
+#ifndef GSS_ESTEP_PRIO
+#define GSS_ESTEP_PRIO 1      // wave priority falling with progress in the register-form E-step
+#endif
 constexpr int EM_TILE = 64;          // frames per tile (one per lane of a wave)
 constexpr int EM_TS = EM_TILE + 1;   // padded LDS row stride (complex elements)
 
@@ -321,6 +327,9 @@ __global__ __launch_bounds__(256) void em_estep_reg_kernel(EmArgs a, const cplx 
     const cplx *Mf = Mq + (int64_t)f * NE * K;
     const cplx *yf = Yn + (int64_t)f * D * T + tc;
 
+#if GSS_ESTEP_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     cplx y[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) y[d] = yf[(int64_t)d * T];
@@ -364,6 +373,14 @@ __global__ __launch_bounds__(256) void em_estep_reg_kernel(EmArgs a, const cplx 
             }
             __builtin_amdgcn_sched_barrier(0);
             ++e;
+#if GSS_ESTEP_PRIO
+            // priority falls with the wave's progress: the waves of a SIMD converge instead
+            // of finishing oldest first, and the end of the launch is not a row of single
+            // waves finishing alone
+            if (e == NE / 4) __builtin_amdgcn_s_setprio(2);
+            if (e == NE / 2) __builtin_amdgcn_s_setprio(1);
+            if (e == 3 * NE / 4) __builtin_amdgcn_s_setprio(0);
+#endif
         }
     }
     // Posterior  pi_k exp(-D ln q_k - ln det_k) / sum  without a logarithm per frame: relative
@@ -1027,6 +1044,9 @@ __device__ __forceinline__ bool class_update_chol(const cplx (&vals)[COV_SLOTS],
     CHOL_STAMP(5);
     if (!chol_inverse_sweep<8, NR, true>(reg, D, A, ld, dinv, tx, ty)) return false;
     CHOL_STAMP(6);
+#if GSS_CHOL_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     double ldv = 0.0;   // ln det B = 2 sum ln U_ii
     for (int i = lane; i < D; i += 64) ldv -= 2.0 * log(dinv[i]);
     ldv = wave_sum(ldv);
@@ -1139,6 +1159,9 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
     const int cnt = plan.S > 0 ? mseg_count(plan, f) : nch;
 
     CHOL_STAMP(0);
+#if GSS_CHOL_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const TriSlots ts = tri_slots_tab(tri_tab, NE, lane);
     const double sg = sum_gamma(Sg, sg_nch, K, k, f, lane);
     const double den = fmax(sg, GSS_TINY);
@@ -1148,6 +1171,9 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
     cplx vals[COV_SLOTS];
     const double tr = reduce_covariance<cov_slots_for(NR)>(Bp, nch, cnt, D, K, k, f, den, vals, lane, ts);
     CHOL_STAMP(3);
+#if GSS_CHOL_PRIO
+    __builtin_amdgcn_s_setprio(2);
+#endif
     bool fast = !force_eigh && tr > 0.0 && isfinite(tr);
     if (fast)
         fast = class_update_chol<NR>(vals, D, K, eig_floor, A, lane, Mq + (int64_t)f * NE * K + k,
