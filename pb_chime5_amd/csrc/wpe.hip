@@ -956,8 +956,12 @@ __device__ inline void chol_update_tile(cplx *A, cplx *Z, int n, int D, int j0, 
     cplx a_cur[TM], b_cur[TN], a_nxt[TM], b_nxt[TN];
     load_ops(0, a_cur, b_cur);
 
-    v4d acc_re[TM][TN], acc_im[TM][TN];
-    // load C in fragment layout: col = li, row = lk + 4 * reg
+    // C -= conj(a) b with THREE real MFMAs per complex product, as in the correlation and the
+    // filter: t1 = sum ar br, t2 = sum ai bi, t3 = sum (ar + ai)(br - bi) accumulate from zero,
+    // re(conj(a) b) = t1 + t2, im = t1 - t2 - t3 are taken off C once at the end (the tile of C
+    // is requested up front and first touched after the loop).  A quarter fewer MFMAs in the
+    // kernel that carries most of the factorisation's flops.
+    cplx cv[TM][TN][4];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -966,43 +970,36 @@ __device__ inline void chol_update_tile(cplx *A, cplx *Z, int n, int D, int j0, 
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = tl.row_off + 16 * a + lk + 4 * reg;
                 const int c = tl.col_off + 16 * b + li;
-                cplx v = c_make(0.0, 0.0);
-                if (r < n && c < ncols) v = tl.is_p ? Z[(int64_t)r * D + c] : A[(int64_t)r * n + c];
-                acc_re[a][b][reg] = v.x;
-                acc_im[a][b][reg] = v.y;
+                cv[a][b][reg] = c_make(0.0, 0.0);
+                if (r < n && c < ncols) cv[a][b][reg] = tl.is_p ? Z[(int64_t)r * D + c] : A[(int64_t)r * n + c];
             }
+    v4d t1[TM][TN], t2[TM][TN], t3[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            t1[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+            t2[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+            t3[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+        }
     for (int ks = 0; ks < ksteps; ++ks) {
         if (PREFETCH) {
             if (ks + 1 < ksteps) load_ops(ks + 1, a_nxt, b_nxt);
         } else if (ks > 0) {
             load_ops(ks, a_cur, b_cur);
         }
-        double nar[TM], nai[TM], ai[TM], br[TN], bi[TN];
+        double as[TM], bd[TN];
 #pragma unroll
-        for (int m = 0; m < TM; ++m) {
-            nar[m] = -a_cur[m].x;
-            nai[m] = -a_cur[m].y;
-            ai[m] = a_cur[m].y;
-        }
+        for (int m = 0; m < TM; ++m) as[m] = a_cur[m].x + a_cur[m].y;
 #pragma unroll
-        for (int m = 0; m < TN; ++m) {
-            br[m] = b_cur[m].x;
-            bi[m] = b_cur[m].y;
-        }
-        // C -= conj(a) b :  re -= ar br + ai bi ;  im -= ar bi - ai br
+        for (int m = 0; m < TN; ++m) bd[m] = b_cur[m].x - b_cur[m].y;
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nar[a], br[b], acc_re[a][b], 0, 0, 0);
-                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nar[a], bi[b], acc_im[a][b], 0, 0, 0);
-            }
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai[a], bi[b], acc_re[a][b], 0, 0, 0);
-                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], br[b], acc_im[a][b], 0, 0, 0);
+                t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[a].x, b_cur[b].x, t1[a][b], 0, 0, 0);
+                t2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[a].y, b_cur[b].y, t2[a][b], 0, 0, 0);
+                t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[a], bd[b], t3[a][b], 0, 0, 0);
             }
         if (PREFETCH) {
 #pragma unroll
@@ -1020,7 +1017,8 @@ __device__ inline void chol_update_tile(cplx *A, cplx *Z, int n, int D, int j0, 
                 const int r = tl.row_off + 16 * a + lk + 4 * reg;
                 const int c = tl.col_off + 16 * b + li;
                 if (r < n && c < ncols) {
-                    const cplx v = c_make(acc_re[a][b][reg], acc_im[a][b][reg]);
+                    const cplx v = c_make(cv[a][b][reg].x - (t1[a][b][reg] + t2[a][b][reg]),
+                                          cv[a][b][reg].y - ((t1[a][b][reg] - t2[a][b][reg]) - t3[a][b][reg]));
                     if (tl.is_p) Z[(int64_t)r * D + c] = v;
                     else A[(int64_t)r * n + c] = v;
                 }
