@@ -928,6 +928,24 @@ def main():
                         'value': steps * utt.seconds / elapsed, 'unit': 'utterance-seconds/s',
                         'channels': resident.D, 'frames': resident.T, 'classes': resident.K,
                         'workload': 'configs[1] (the headline)', 'mode': 'one stream, inputs resident in HBM'}
+        # the accuracy switch of the correlation (GSS_CORR_BLOCKED=1: chunk-wise accumulation
+        # of R and P, read by the library on every call): what it costs on the headline
+        os.environ['GSS_CORR_BLOCKED'] = '1'
+        try:
+            ms_b, res_b = time_resident(ctx, ops, utt, params, 10)
+            prof_b = profile_kernels(ctx, res_b, utt, PROFILE_STEPS)
+        finally:
+            del os.environ['GSS_CORR_BLOCKED']
+        configs['2-corr-blocked'] = {
+            'ms_per_utterance': ms_b, 'utterance_seconds': utt.seconds,
+            'value': 1e3 * utt.seconds / ms_b, 'unit': 'utterance-seconds/s',
+            'wpe_corr_ms_per_launch': prof_b['wpe_corr']['ms'] / prof_b['wpe_corr']['calls'],
+            'wpe_corr_ms_per_launch_default': prof_all['wpe_corr']['ms'] / prof_all['wpe_corr']['calls'],
+            'workload': 'configs[1] with GSS_CORR_BLOCKED=1 (default: off)',
+            'what': 'R and P summed in 64-frame blocks (64 + T / 64 roundings per sum instead of T): the '
+                    'distance from an extended-precision WPE falls from 1.8 - 2.0 x the oracle\'s own to '
+                    '1.1 - 1.4 x (tests/test_gpu_stages.py, tools/wpe_accuracy.py)',
+            'mode': 'one stream, inputs resident in HBM'}
         sr = SR
         n3 = 554490                          # synthetic.config3_item(0): 4.66 s core + 2 x 15 s
         iv3 = [(240000, n3 - 240000), (100000, 400000), (50000, 250000), (300000, 520000)]

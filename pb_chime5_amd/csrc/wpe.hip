@@ -559,7 +559,13 @@ __device__ __forceinline__ int corr_fetch(int *counters, int F, int xcd, int &li
     return -1;
 }
 
-template <bool M3, int MASK, int NW, class Issue>
+// BLOCKED (GSS_CORR_BLOCKED=1): the sums of every 64-frame chunk start from zero and are added
+// to the totals (re, im: two accumulators per tile next to the three of the 3M form, +64
+// registers) when the chunk is done -- a sum over T frames is then 64 + T / 64 roundings deep
+// instead of T.  The f64 MFMA rounds after every frame; BLAS, which the reference's einsum
+// runs on, sums in blocks: this is the factor 1.8 - 2 between this path and the oracle in
+// their distances from an extended-precision WPE (tests: ..._extended_precision).
+template <bool M3, int MASK, int NW, bool BLOCKED, class Issue>
 __device__ __forceinline__ void corr_item_dma(
     int64_t T, int D, int n, int c, int win, cplx *S0, double *w0, const CorrTile tl, bool active,
     int f, int f_next, int &b, Issue &issue, int *ring_slot, int fetched, cplx *__restrict__ R,
@@ -567,6 +573,13 @@ __device__ __forceinline__ void corr_item_dma(
     constexpr int TS = 2;
     v4d t1[TS][TS], t2[TS][TS], t3[TS][TS];
     corr_zero<TS>(t1, t2, t3);
+    v4d sre[BLOCKED ? TS : 1][BLOCKED ? TS : 1], sim[BLOCKED ? TS : 1][BLOCKED ? TS : 1];
+    if constexpr (BLOCKED) {
+#pragma unroll
+        for (int a = 0; a < TS; ++a)
+#pragma unroll
+            for (int bb = 0; bb < TS; ++bb) sre[a][bb] = sim[a][bb] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
     for (int64_t t0 = 0; t0 < T; t0 += CORR_KT, b ^= 1) {
 #ifdef GSS_CORR_TRACE
         const long long ta = clock64();
@@ -582,6 +595,20 @@ __device__ __forceinline__ void corr_item_dma(
         const long long tb = clock64();
 #endif
         if (active) corr_chunk<TS, M3, MASK>(S0 + b * win, w0 + b * CORR_KT, D, tl, t1, t2, t3);
+        if constexpr (BLOCKED) if (active) {
+#pragma unroll
+            for (int a = 0; a < TS; ++a)
+#pragma unroll
+                for (int bb = 0; bb < TS; ++bb) {
+                    if (!((MASK >> (a * TS + bb)) & 1)) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sre[a][bb][r] += t1[a][bb][r] + t2[a][bb][r];
+                        sim[a][bb][r] += (t3[a][bb][r] - t1[a][bb][r]) + t2[a][bb][r];
+                    }
+                    t1[a][bb] = t2[a][bb] = t3[a][bb] = (v4d){0.0, 0.0, 0.0, 0.0};
+                }
+        }
         // the item fetched at the start of this one (its atomic has had a chunk to return):
         // into the ring slot of the previous item, published by the barrier below
         if (t0 == 0 && threadIdx.x == 0) *ring_slot = fetched;
@@ -606,10 +633,13 @@ __device__ __forceinline__ void corr_item_dma(
 #else
     if (active)
 #endif
-        corr_store<TS, M3, MASK>(tl, f, n, c, D, t1, t2, t3, R, P);
+    {
+        if constexpr (BLOCKED) corr_store<TS, false, MASK>(tl, f, n, c, D, sre, sre, sim, R, P);    // (re, -, im)
+        else corr_store<TS, M3, MASK>(tl, f, n, c, D, t1, t2, t3, R, P);
+    }
 }
 
-template <bool M3, int NW>
+template <bool M3, int NW, bool BLOCKED = false>
 __global__ __launch_bounds__(64 * NW) void wpe_corr_persist_kernel(
     const cplx *__restrict__ Y, const double *__restrict__ w, int F, int64_t T, int D, int n,
     int c, int pieces, const CorrTile *__restrict__ tiles, int ntiles, CorrQueue cq,
@@ -699,7 +729,7 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_persist_kernel(
         int *ring_slot = &ring[(k + 2) % 3];
 #define CORR_CASE(M)                                                                              \
     case M:                                                                                       \
-        corr_item_dma<M3, M, NW>(T, D, n, c, win, S0, w0, tl, active, f, next < 0 ? -1 : next >> 12, \
+        corr_item_dma<M3, M, NW, BLOCKED>(T, D, n, c, win, S0, w0, tl, active, f, next < 0 ? -1 : next >> 12, \
                                  b, issue, ring_slot, fetched, R, P);                             \
         break
         switch (mask) {
@@ -708,7 +738,7 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_persist_kernel(
             CORR_CASE(5);
             CORR_CASE(11);
             default:
-                corr_item_dma<M3, 15, NW>(T, D, n, c, win, S0, w0, tl, active, f,
+                corr_item_dma<M3, 15, NW, BLOCKED>(T, D, n, c, win, S0, w0, tl, active, f,
                                           next < 0 ? -1 : next >> 12, b, issue, ring_slot, fetched,
                                           R, P);
         }
@@ -1948,7 +1978,12 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     // ... as resident workgroups fed from per-XCD item queues (GSS_CORR_PERSIST=0: one
     // workgroup per item)
     const bool corr_persist = corr_dma && !(getenv("GSS_CORR_PERSIST") && atoi(getenv("GSS_CORR_PERSIST")) == 0);
-    auto corr_persist_fn = corr_nw == 2 ? wpe_corr_persist_kernel<true, 2> : wpe_corr_persist_kernel<true, 4>;
+    // GSS_CORR_BLOCKED=1 (read on every call): chunk-wise accumulation of R and P
+    const bool corr_blocked = corr_persist && getenv("GSS_CORR_BLOCKED") && atoi(getenv("GSS_CORR_BLOCKED")) != 0;
+    auto corr_persist_fn = corr_blocked ? (corr_nw == 2 ? wpe_corr_persist_kernel<true, 2, true>
+                                                        : wpe_corr_persist_kernel<true, 4, true>)
+                                        : (corr_nw == 2 ? wpe_corr_persist_kernel<true, 2>
+                                                        : wpe_corr_persist_kernel<true, 4>);
     CorrQueue corr_queue{(ntiles + corr_nw - 1) / corr_nw, 0};
     int corr_slots = 0;
     if (corr_persist) {

@@ -156,7 +156,8 @@ def test_wpe_matches_oracle(gpu_ctx, D, T, F, taps, delay, iters):
     assert gpu_ctx.last_wpe_zero_pivots() == 0
 
 
-def test_wpe_config2_bins_within_oracle_noise_of_extended_precision(gpu_ctx, golden):
+@pytest.mark.parametrize('blocked', [False, True])
+def test_wpe_config2_bins_within_oracle_noise_of_extended_precision(gpu_ctx, golden, monkeypatch, blocked):
     """Three bins of the bench workload (24 channels, T = 941, 10 taps; bin 169 was the worst
     bin of the end-to-end test in rounds 1-2) against the weighted least-squares iteration
     evaluated in 80-bit extended precision (tests/golden/make_wpe_truth.py).  float64
@@ -168,6 +169,11 @@ def test_wpe_config2_bins_within_oracle_noise_of_extended_precision(gpu_ctx, gol
     MFMA rounds after every one of the 941 frames, BLAS sums in blocks -- a NumPy
     restatement that accumulates frame by frame lands on the same 1.8e-11 in bin 169)."""
     from pb_chime5_amd import ops
+    # GSS_CORR_BLOCKED=1: R and P summed in 64-frame blocks like BLAS does -- within 1.6 x of the
+    # oracle's own distance (measured 1.1 - 1.4 x); the default is the frame-by-frame sum
+    if blocked:
+        monkeypatch.setenv('GSS_CORR_BLOCKED', '1')
+    bound = 1.6 if blocked else 3.0
     g = golden('wpe_truth_config2.npz')
     Y, taps, delay = g['Y'], int(g['taps']), int(g['delay'])
     n = np.linalg.norm
@@ -179,7 +185,7 @@ def test_wpe_config2_bins_within_oracle_noise_of_extended_precision(gpu_ctx, gol
             e_or, e_gpu = n(want[..., i] - t) / n(t), n(got[..., i] - t) / n(t)
             print(f'iterations {iters} bin {int(f)}: oracle {e_or:.2e} gpu {e_gpu:.2e} '
                   f'({e_gpu / e_or:.2f}x), gpu vs oracle {n(got[..., i] - want[..., i]) / n(t):.2e}')
-            assert e_gpu < 3 * e_or, (iters, int(f), e_gpu, e_or)
+            assert e_gpu < bound * e_or, (iters, int(f), blocked, e_gpu, e_or)
             assert e_or < (1e-9 if iters == 1 else 1e-7)
     assert gpu_ctx.last_wpe_zero_pivots() == 0
 
