@@ -533,18 +533,28 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_dma_kernel(
 // items ahead.
 struct CorrQueue {
     int ngroups, gh;      // tile groups per frequency; the first gh are "heavy"
+    int fblock;           // frequencies per queue block (heavy groups of a block, then its light ones)
 };
 
 __device__ __forceinline__ int corr_queue_len(int F, int x) { return (F - x + 7) / 8; }
 
-// item q of queue x -> f * 4096 + group
+// item q of queue x -> f * 4096 + group.  The queue of an XCD walks its frequencies in blocks
+// of `fblock`: the heavy tile groups of the block's frequencies first, then their light ones
+// (fewer needed sub-tiles per wave), so that the launch ends on short items AND the light
+// groups of a frequency run soon after its heavy ones, while its slab is still in the XCD's
+// L2 (heavy groups of ALL frequencies first -- fblock >= the queue's length -- fetched the
+// slab 3.2 times per launch: profiles/r04d_traffic.json).
 __device__ __forceinline__ int corr_queue_item(int F, int x, int q, const CorrQueue cq) {
     const int nf = corr_queue_len(F, x);
-    const int heavy = nf * cq.gh;
-    if (q < heavy) return (x + 8 * (q / cq.gh)) * 4096 + q % cq.gh;
+    const int per_block = cq.fblock * cq.ngroups;
+    const int blk = q / per_block;
+    q -= blk * per_block;
+    const int j0 = blk * cq.fblock, nfb = min(cq.fblock, nf - j0);
+    const int heavy = nfb * cq.gh;
+    if (q < heavy) return (x + 8 * (j0 + q / cq.gh)) * 4096 + q % cq.gh;
     q -= heavy;
     const int gl = max(cq.ngroups - cq.gh, 1);
-    return (x + 8 * (q / gl)) * 4096 + cq.gh + q % gl;
+    return (x + 8 * (j0 + q / gl)) * 4096 + cq.gh + q % gl;
 }
 
 // next item for this workgroup (thread 0 only): own XCD's queue first, then the others;
@@ -1984,12 +1994,18 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                                                         : wpe_corr_persist_kernel<true, 4, true>)
                                         : (corr_nw == 2 ? wpe_corr_persist_kernel<true, 2>
                                                         : wpe_corr_persist_kernel<true, 4>);
-    CorrQueue corr_queue{(ntiles + corr_nw - 1) / corr_nw, 0};
+    CorrQueue corr_queue{(ntiles + corr_nw - 1) / corr_nw, 0, 1 << 20};
     int corr_slots = 0;
     if (corr_persist) {
         // heavy groups: the heaviest wave needs 3 or 4 of its tile's 4 sub-tiles
         for (int g = 0; g < corr_queue.ngroups; ++g)
             if (__builtin_popcount(tiles[g * corr_nw].mask) >= 3) corr_queue.gh = g + 1;
+        // GSS_CORR_FMAJOR=1: all groups of a frequency adjacent in the queue (its slab is
+        // fetched into the XCD's L2 once) instead of the heavy groups of all frequencies first
+        if (getenv("GSS_CORR_FMAJOR") && atoi(getenv("GSS_CORR_FMAJOR")) != 0) corr_queue.gh = corr_queue.ngroups;
+        // frequencies per queue block (GSS_CORR_QBLOCK; 0: heavy groups of all frequencies first)
+        const int qb = getenv("GSS_CORR_QBLOCK") ? atoi(getenv("GSS_CORR_QBLOCK")) : 0;
+        corr_queue.fblock = qb > 0 ? qb : 1 << 20;
         if (corr_dma_lds > 64 * 1024)
             GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(corr_persist_fn),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -12,7 +12,7 @@ bench.py uses.
 import collections, csv, glob, json, re, sys
 
 LABELS = [
-    ('wpe_corr_kernel', 'wpe_corr'), ('wpe_apply_kernel', 'wpe_apply'), ('wpe_power_kernel', 'wpe_power'),
+    ('wpe_corr_persist_kernel', 'wpe_corr'), ('wpe_corr_dma_kernel', 'wpe_corr'), ('wpe_corr_kernel', 'wpe_corr'), ('wpe_apply_kernel', 'wpe_apply'), ('wpe_power_kernel', 'wpe_power'),
     ('chol_update_kernel', 'wpe_chol_update'), ('chol_diag_kernel', 'wpe_chol_diag'),
     ('chol_trsm_kernel', 'wpe_chol_trsm'), ('chol_backsolve_kernel', 'wpe_backsolve'),
     ('em_estep_reg_kernel', 'em_estep'), ('em_estep_kernel', 'em_estep_first'),
