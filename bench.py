@@ -487,8 +487,9 @@ def em_loop_entry(prof, steps, iterations, F, T, D, K, roofline):
             'hbm_frac': by / sec / 1e9 / roofline.PEAK_HBM_GBS,
             'executed_flops_per_iteration': flops,
             'valu_f64_frac': flops / sec / 1e12 / roofline.PEAK_F64_TFLOPS,
-            'binding_roof': 'latency / VALU issue at 2 workgroups per CU (513 frequencies on 256 '
-                            'CUs; tools/em4_trace.py)',
+            'binding_roof': 'VALU issue at 2 workgroups per CU (513 frequencies on 256 CUs): phase E runs '
+                            'at 8 cycles per instruction with two waves per SIMD; 27 % of the kernel is the '
+                            'per-iteration sums + class update (tools/em4_trace.py, DESIGN 8.13)',
         }
     names = [n for n in ('em_estep', 'em_mstep', 'em_chol', 'em_eigh') if n in prof]
     ms_iter = sum(prof[n]['ms'] for n in names) / steps / iterations

@@ -739,7 +739,9 @@ def test_kernel_variants_agree(gpu_ctx, D, monkeypatch):
     vs 32 x 32 correlation tiles, 3- vs 4-product complex MFMA forms (correlation and filter
     application), the filter application with 1 - 4 frame phases packed into the column
     dimension, register-form vs tiled M-step (D = 4), register- vs LDS-form E-step,
-    Cholesky vs eigendecomposition model update.  Same arithmetic up to summation order."""
+    Cholesky vs eigendecomposition model update, chunked vs statically partitioned M-step, the
+    one-launch EM of one array vs three launches per iteration, the correlation kernel's forms.
+    Same arithmetic up to summation order."""
     from pb_chime5_amd import ops, synthetic
     # (frames per unknown and sensor noise as in test_other_channel_and_class_counts: a
     # well-conditioned WPE, so that summation order does not decide the result)
@@ -764,7 +766,13 @@ def test_kernel_variants_agree(gpu_ctx, D, monkeypatch):
                 {'GSS_MSTEP_TILED': '1'}, {'GSS_ESTEP_LDS': '1'}, {'GSS_FORCE_EIGH': '1'},
                 {'GSS_CORR_NW': '2'}, {'GSS_APPLY_NWV': '2'}, {'GSS_CHOL_DIAG_UNFOLDED': '1'},
                 {'GSS_APPLY_PH': '1'}, {'GSS_APPLY_PH': '2'},
-                {'GSS_APPLY_PH': '3'}, {'GSS_APPLY_PH': '4'}):
+                {'GSS_APPLY_PH': '3'}, {'GSS_APPLY_PH': '4'},
+                # round 4: M-step in chunks instead of the static partition, the one-array EM
+                # as separate launches, correlation variants (one workgroup per item, other
+                # queue orders, block-wise accumulation)
+                {'GSS_MSTEP_CHUNKED': '1'}, {'GSS_MSTEP_SLOTS': '100'}, {'GSS_EM_UNFUSED': '1'},
+                {'GSS_CORR_PERSIST': '0'}, {'GSS_CORR_QBLOCK': '4'}, {'GSS_CORR_FMAJOR': '1'},
+                {'GSS_CORR_BLOCKED': '1'}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         other, odet = run()
