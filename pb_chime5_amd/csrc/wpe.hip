@@ -785,6 +785,9 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_persist_kernel(
 // A non-positive pivot (exactly singular system, e.g. an all-zero channel) zeroes
 // that row, which reproduces the minimum-norm lstsq fallback of stable_solve
 // (pb_chime5/math/solve.py:95-114) for zero rows / columns.
+#ifndef GSS_UPD_PREFETCH
+#define GSS_UPD_PREFETCH 1     // k-steps of operands in flight beyond the next one (chol_update)
+#endif
 constexpr int CH_NB = 48;
 constexpr int UD_LD = CH_NB + 1;   // LDS leading dimension of the diagonal block (bank spread)
 
@@ -993,7 +996,7 @@ __device__ inline void chol_update_tile(cplx *A, cplx *Z, int n, int D, int j0, 
     };
 
     const int ksteps = (nb + 3) / 4;
-    cplx a_cur[TM], b_cur[TN], a_nxt[TM], b_nxt[TN];
+    cplx a_cur[TM], b_cur[TN];
     load_ops(0, a_cur, b_cur);
 
     // C -= conj(a) b with THREE real MFMAs per complex product, as in the correlation and the
@@ -1022,9 +1025,19 @@ __device__ inline void chol_update_tile(cplx *A, cplx *Z, int n, int D, int j0, 
             t2[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
             t3[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
         }
+    // operands 1 + PD k-steps ahead in a register ring (one k-step ahead was not enough: an L2
+    // round trip is three k-steps of MFMA time for one wave; J1 at config 2 with 1 / 2 / 3 / 4 /
+    // 6 k-steps ahead: 153.8 / 147.6 / 168.5 / 173.3 / 193.4 us -- the ring's register moves
+    // and the occupancy cost more than the latency beyond two)
+    constexpr int PD = GSS_UPD_PREFETCH;
+    cplx a_ring[PD][TM], b_ring[PD][TN];
+#pragma unroll
+    for (int p = 0; p < PD; ++p)
+        if (PREFETCH && p + 1 < ksteps) load_ops(p + 1, a_ring[p], b_ring[p]);
     for (int ks = 0; ks < ksteps; ++ks) {
+        cplx a_new[TM], b_new[TN];
         if (PREFETCH) {
-            if (ks + 1 < ksteps) load_ops(ks + 1, a_nxt, b_nxt);
+            if (ks + PD + 1 < ksteps) load_ops(ks + PD + 1, a_new, b_new);
         } else if (ks > 0) {
             load_ops(ks, a_cur, b_cur);
         }
@@ -1043,9 +1056,19 @@ __device__ inline void chol_update_tile(cplx *A, cplx *Z, int n, int D, int j0, 
             }
         if (PREFETCH) {
 #pragma unroll
-            for (int m = 0; m < TM; ++m) a_cur[m] = a_nxt[m];
+            for (int m = 0; m < TM; ++m) {
+                a_cur[m] = a_ring[0][m];
 #pragma unroll
-            for (int m = 0; m < TN; ++m) b_cur[m] = b_nxt[m];
+                for (int p = 0; p + 1 < PD; ++p) a_ring[p][m] = a_ring[p + 1][m];
+                a_ring[PD - 1][m] = a_new[m];
+            }
+#pragma unroll
+            for (int m = 0; m < TN; ++m) {
+                b_cur[m] = b_ring[0][m];
+#pragma unroll
+                for (int p = 0; p + 1 < PD; ++p) b_ring[p][m] = b_ring[p + 1][m];
+                b_ring[PD - 1][m] = b_new[m];
+            }
         }
     }
 #pragma unroll
