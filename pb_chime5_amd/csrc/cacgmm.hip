@@ -52,7 +52,8 @@ __device__ __forceinline__ void set_progress_priority(int done, int total) {
     else __builtin_amdgcn_s_setprio(0);
 }
 
-// Static balanced partition of the M-step (D > 12): the (frequency, 64-frame tile) items of an
+// Static balanced partition of the M-step (D > 4; measured at T = 2172: D = 8 / 10 / 12 / 24
+// -25 / -21 / -18 / -14 % against equal chunks per frequency): the (frequency, 64-frame tile) items of an
 // utterance, frequency major, are cut into S equal runs, one per RESIDENT workgroup (S = what
 // the chip holds at once), instead of F x nch workgroups of nch equal chunks per frequency:
 // every workgroup starts at t = 0 and ends with the others (the chunked launch drained for
@@ -1939,12 +1940,14 @@ int launch_estep_reg_k(gss_ctx *ctx, int K, int mode, const EmArgs &a, const cpl
 // Resident workgroups of the M-step kernel on this device (static partition: one run of
 // items each).
 template <int KW>
-int mstep_resident_slots(gss_ctx *ctx, int D, int *slots) {
+int mstep_resident_slots(gss_ctx *ctx, int D, bool prefetch, int *slots) {
     const size_t lds = wcov_lds_layout(D, KW).total;
-    GSS_TRY(raise_lds_limit(ctx, wcov_kernel<KW, false, true>, lds));
+    const void *fn = prefetch ? reinterpret_cast<const void *>(wcov_kernel<KW, false, true, true>)
+                              : reinterpret_cast<const void *>(wcov_kernel<KW, false, true>);
+    if (lds > 64 * 1024)
+        GSS_HIP_CHECK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0, cus = 0;
-    GSS_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                           &per_cu, reinterpret_cast<const void *>(wcov_kernel<KW, false, true>), 256, lds));
+    GSS_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
     GSS_HIP_CHECK(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
     *slots = std::max(per_cu, 1) * cus;
     return GSS_OK;
@@ -1972,9 +1975,10 @@ int launch_mstep(gss_ctx *ctx, const EmArgs &a, const cplx *Yn, int F, int K, in
         // 0.130 / 0.118)
         if (a.D <= mstep_prefetch_max_d()) {
             GSS_TRY(raise_lds_limit(ctx, wcov_kernel<KW, false, true, true>, lds));
-            hipLaunchKernelGGL((wcov_kernel<KW, false, true, true>), dim3(xcd_grid(a.nch, F)),
+            hipLaunchKernelGGL((wcov_kernel<KW, false, true, true>),
+                               dim3(a.mseg.S > 0 ? a.mseg.S : xcd_grid(a.nch, F)),
                                dim3(256), lds, ctx->stream, Yn, a.W, F, a.T, a.D, a.NE, a.nch,
-                               a.chunk_frames, a.Bp, K, k0, MsegPlan{});
+                               a.chunk_frames, a.Bp, K, k0, a.mseg);
         } else {
             GSS_TRY(raise_lds_limit(ctx, wcov_kernel<KW, false, true>, lds));
             const dim3 grid(a.mseg.S > 0 ? a.mseg.S : xcd_grid(a.nch, F));
@@ -2030,19 +2034,20 @@ int launch_mstep_k(gss_ctx *ctx, int K, const EmArgs &a, const cplx *Yn, int F) 
     return GSS_OK;
 }
 
-int mstep_resident_slots_k(gss_ctx *ctx, int KW, int D, int *slots) {
-    GSS_K_SWITCH8(KW, mstep_resident_slots<KK>(ctx, D, slots));
+int mstep_resident_slots_k(gss_ctx *ctx, int KW, int D, bool prefetch, int *slots) {
+    GSS_K_SWITCH8(KW, mstep_resident_slots<KK>(ctx, D, prefetch, slots));
     return gss_fail(ctx, GSS_ERR_UNSUPPORTED, "cacgmm: KW=%d", KW);
 }
 
 // The M-step's static partition for (F, T) on this device; S = 0 where the chunked form stays
-// (one array, the prefetching form of few channels, GSS_MSTEP_CHUNKED=1).
+// (one array, GSS_MSTEP_CHUNKED=1, few frequencies).
 int mstep_plan(gss_ctx *ctx, int F, int64_t T, int D, int K, MsegPlan *plan) {
     *plan = MsegPlan{};
-    if (D <= mstep_prefetch_max_d() || getenv("GSS_MSTEP_CHUNKED") != nullptr) return GSS_OK;
+    static const int min_d = getenv("GSS_MSTEP_PLAN_MIN_D") ? atoi(getenv("GSS_MSTEP_PLAN_MIN_D")) : 5;
+    if (D < min_d || D <= 4 || getenv("GSS_MSTEP_CHUNKED") != nullptr) return GSS_OK;
     const int ngroups = (K + 7) / 8, per = (K + ngroups - 1) / ngroups;
     int slots = 0;
-    GSS_TRY(mstep_resident_slots_k(ctx, per, D, &slots));
+    GSS_TRY(mstep_resident_slots_k(ctx, per, D, D <= mstep_prefetch_max_d(), &slots));
     if (const char *e = getenv("GSS_MSTEP_SLOTS")) slots = std::max(1, atoi(e));
     const int64_t ntile = (T + EM_TILE - 1) / EM_TILE, N = ntile * F;
     if (N >= (1LL << 30) || ntile < 1) return GSS_OK;
