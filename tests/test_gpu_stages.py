@@ -387,6 +387,21 @@ def test_cacgmm_one_array_kernel_equals_three_launch_path(gpu_ctx, monkeypatch, 
     assert np.max(np.abs(one - want)) < 1e-7
 
 
+def test_cacgmm_one_array_shared_last_frequency(gpu_ctx, monkeypatch):
+    """GSS_EM4_COOP=g (off by default): g workgroups of the one-launch EM share the chunks of the
+    last frequency and exchange sums and model through agent-scope atomics.  Same posteriors up
+    to the order of the sums."""
+    from pb_chime5_amd import ops
+    rng = np.random.default_rng(7)
+    Y, act = _scene(rng, 4, 1100, 9, 3)
+    base = ops.cacgmm_posteriors(Y, act, 6, 1, ctx=gpu_ctx)
+    for g in (2, 5):
+        monkeypatch.setenv('GSS_EM4_COOP', str(g))
+        coop = ops.cacgmm_posteriors(Y, act, 6, 1, ctx=gpu_ctx)
+        monkeypatch.delenv('GSS_EM4_COOP')
+        assert np.max(np.abs(coop - base)) < 1e-9, g
+
+
 def test_cacgmm_class_with_fewer_frames_than_channels(gpu_ctx):
     """Found by the wide fuzz sweep (GSS_FUZZ_SEED=202 GSS_FUZZ_WIDE=1, case 220, bin 43): 29
     channels, 110 frames, and after the first iteration the noise class is left with five
