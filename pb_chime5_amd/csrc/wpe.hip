@@ -1760,6 +1760,24 @@ static int corr_tiles(int n, int D, int c, int ct, std::vector<CorrTile> &tiles)
     return (int)tiles.size();
 }
 
+// 16 x 32 (R) and 32 x 16 (P) wave tiles for the channel counts between one array and the
+// 32 x 32 tiling (D = 8 ... 12 at 10 taps): pairs of needed 16 x 16 sub-tiles -- two column
+// sub-tiles of one row for R (mask 3), two row sub-tiles of one column for P (mask 5) -- run
+// through the 32 x 32 kernels, whose masks skip the other half of the tile with its operand
+// loads.  Every wave carries two sub-tiles (the odd one of a row: one): 6 MFMAs per 5 operand
+// products and k-step, where one sub-tile per wave has 3 per 4 and the 32 x 32 tiling leaves
+// the four waves of a workgroup with 4, 3, 2 and 1 sub-tiles at n = 120.
+static int corr_tiles_pairs(int n, int D, int c, std::vector<CorrTile> &tiles) {
+    for (int r0 = 0; r0 < n; r0 += 16)
+        for (int c0 = r0; c0 < n; c0 += 32) tiles.push_back({r0, c0, 0, c0 + 16 < n ? 3 : 1});
+    for (int r0 = 0; r0 < n; r0 += 32)
+        for (int c0 = 0; c0 < D; c0 += 16) tiles.push_back({r0, c * D + c0, 1, r0 + 16 < n ? 5 : 1});
+    std::stable_sort(tiles.begin(), tiles.end(), [](const CorrTile &x, const CorrTile &y) {
+        return __builtin_popcount(x.mask) > __builtin_popcount(y.mask);
+    });
+    return (int)tiles.size();
+}
+
 static int corr_padf(int D, int ct) { return (ct + D - 1) / D + 1; }
 
 size_t wpe_workspace_bytes(int F, int64_t T, int D, int taps, int delay) {
@@ -1823,8 +1841,13 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     // D = 24: 4.16 -> 5.11.
     const int sub16 = (n + 15) / 16;
     int corr_ts = sub16 * (sub16 + 1) / 2 + sub16 * ((D + 15) / 16) <= CORR_FINE_MAX_SUBTILES ? 1 : 2;
-    if (const char *e = getenv("GSS_CORR_TS")) corr_ts = atoi(e) == 1 ? 1 : 2;
-    const int ntiles = corr_tiles(n, D, c, 16 * corr_ts, tiles);
+    // GSS_CORR_TS=3: the pair tiling (corr_tiles_pairs) on the 32 x 32 kernels
+    bool corr_pairs = false;
+    if (const char *e = getenv("GSS_CORR_TS")) {
+        corr_ts = atoi(e) == 1 ? 1 : 2;
+        corr_pairs = atoi(e) == 3;
+    }
+    const int ntiles = corr_pairs ? corr_tiles_pairs(n, D, c, tiles) : corr_tiles(n, D, c, 16 * corr_ts, tiles);
     // trailing-update tiles: 16 x 16, every tile that reaches the upper triangle (larger
     // register tiles -- 2 x 2, 1 x 2, 2 x 1 MFMA tiles per wave -- measured slower: the update
     // is bound by the read-modify-write of the trailing matrix and wants many small
@@ -1865,7 +1888,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                 "wpe: taps*D=%d too large", n);
     static_assert(sizeof(CorrTile) == sizeof(UpdTile), "tile structs share one buffer");
     if (ctx->wpe_tiles_key[0] != taps || ctx->wpe_tiles_key[1] != delay ||
-        ctx->wpe_tiles_key[2] != D || ctx->wpe_tiles_key[3] != corr_ts + (fold_diag ? 0 : 16)) {
+        ctx->wpe_tiles_key[2] != D || ctx->wpe_tiles_key[3] != corr_ts + (fold_diag ? 0 : 16) + (corr_pairs ? 32 : 0)) {
         GSS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (!ctx->wpe_tiles)
             GSS_HIP_CHECK(ctx, hipMalloc(&ctx->wpe_tiles, sizeof(CorrTile) * (1024 + 4096 + 1 + 64)));
@@ -1878,7 +1901,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         ctx->wpe_tiles_key[0] = taps;
         ctx->wpe_tiles_key[1] = delay;
         ctx->wpe_tiles_key[2] = D;
-        ctx->wpe_tiles_key[3] = corr_ts + (fold_diag ? 0 : 16);
+        ctx->wpe_tiles_key[3] = corr_ts + (fold_diag ? 0 : 16) + (corr_pairs ? 32 : 0);
     }
     CorrTile *tiles_dev = reinterpret_cast<CorrTile *>(ctx->wpe_tiles);
     UpdTile *upd_dev = reinterpret_cast<UpdTile *>(tiles_dev + 1024);
