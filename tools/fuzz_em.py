@@ -57,6 +57,9 @@ def main():
         obs = np.einsum('fkd,fkt->dtf', steer, src)
         obs = obs + 10.0 ** rng.uniform(-2, 0) * (rng.standard_normal(obs.shape) + 1j * rng.standard_normal(obs.shape))
         tag = dict(case=case, D=D, K=K, T=T, F=F, it=it, post=post, active=act.sum(axis=1).tolist())
+        # GSS_FUZZ_ONLY=case: replay one case of the stream (the draws of the others are consumed)
+        if os.environ.get('GSS_FUZZ_ONLY') and case != int(os.environ['GSS_FUZZ_ONLY']):
+            continue
         res = {}
         for side, fn in (('oracle', lambda: oracle.gss_block_batched(obs, act, iterations=it, iterations_post=post)),
                          ('gpu', lambda: ops.cacgmm_posteriors(obs, act, it, post))):
@@ -84,6 +87,8 @@ def main():
         d_ob = np.max(np.abs(o[..., f] - b))
         d_gof = np.max(np.abs(g[..., f] - o[..., f]))
         worst_ratio = max(worst_ratio, d_gof / max(d_ob, 1e-9))
+        if os.environ.get('GSS_FUZZ_ONLY'):
+            print('replay: GPU-oracle', d_gof, 'oracle-brute', d_ob, 'GPU-brute', np.max(np.abs(g[..., f] - b)), tag)
         if not d_gof <= 30 * d_ob + 1e-8:
             print('EM', d_gof, 'oracle-brute', d_ob, 'frequency', f, tag)
             bad += 1
