@@ -1343,7 +1343,10 @@ __global__ __launch_bounds__(256, 3) void chol_backsolve_kernel(const cplx *__re
 // every MFMA and wait for each result.
 // M3: three real MFMAs per complex product as in the correlation (t1 = sum ur gr,
 // t2 = sum ui gi, t3 = sum (ur + ui)(gr - gi); re = t1 + t2, im = t3 - t1 + t2).
-template <int TA, int NB, bool M3, int NWV = 4>
+// WRAPS: carries of the running (r / D, r % D) per k-step -- one is enough from D = 4 on (r
+// advances by 4), and every wrap is three VALU instructions that the MFMA pipe waits for.
+// TAIL: n is not a multiple of 4 (the last k-step's rows r >= n have to be masked).
+template <int TA, int NB, bool M3, int NWV = 4, int WRAPS = 4, bool TAIL = true>
 __global__ __launch_bounds__(64 * NWV) void wpe_apply_kernel(const cplx *__restrict__ Y,
                                                         const cplx *__restrict__ G, int F,
                                                         int64_t T, int D, int n, int c,
@@ -1363,7 +1366,11 @@ __global__ __launch_bounds__(64 * NWV) void wpe_apply_kernel(const cplx *__restr
     // dependent round trips as long as the whole k loop)
     constexpr int PRE = 14, NT = 64 * NWV;
     const int total = frames_lds * D;
+#ifdef GSS_EXP_APPLY_NOSTAGE     // timing-only ablation: the window is not staged (garbage results)
+    for (int base = 0; base < (T < 0 ? total : 0); base += NT * PRE) {
+#else
     for (int base = 0; base < total; base += NT * PRE) {
+#endif
         cplx v[PRE];
 #pragma unroll
         for (int j = 0; j < PRE; ++j) {
@@ -1401,26 +1408,44 @@ __global__ __launch_bounds__(64 * NWV) void wpe_apply_kernel(const cplx *__restr
     // in VGPRs and copies them to AGPRs and back around every group of MFMAs.
     const int ksteps = (n + 3) / 4;
     const int lds_last = frames_lds * DP - 1;
-    auto load_g = [&](int ks, cplx (&g)[NB]) {
-        const int rc = min(4 * ks + lk, n - 1);
+    // Operand addresses are ADVANCED, not recomputed: every integer VALU instruction of the k
+    // loop is time the f64 MFMA pipe of this SIMD does not get, and the 64-bit
+    // multiply-adds of "row * D + column" were the most expensive of them.  G: one 32-bit
+    // element offset per channel tile, + 4 D per k-step, clamped to the last row (k-steps
+    // past the end are requested and never used).  Window: lin = (r / D) DP + r % D of the
+    // running row r = 4 ks + lk, + 4 per k-step, + DP - D when r % D wraps.
+    int goff[NB], goff_max[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) g[b] = Gf[(int64_t)rc * D + min(16 * b + li, D - 1)];
+    for (int b = 0; b < NB; ++b) {
+        const int col = min(16 * b + li, D - 1);
+        goff[b] = min(lk, n - 1) * D + col;
+        goff_max[b] = (n - 1) * D + col;
+    }
+    auto load_g = [&](int, cplx (&g)[NB]) {      // (k-steps are requested in order)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            g[b] = Gf[goff[b]];
+            goff[b] = min(goff[b] + 4 * D, goff_max[b]);
+        }
     };
-    // r = 4 ks + lk = rq D + rm, advanced without dividing
-    int rq = lk / D, rm = lk - rq * D;
+    int rm = lk % D, lin = (lk / D) * DP + rm;
+    int ubase[TA];
+#pragma unroll
+    for (int a = 0; a < TA; ++a) ubase[a] = (wf0 + 16 * a + li) * DP;
     auto load_u = [&](cplx (&u)[TA]) {
 #pragma unroll
-        for (int a = 0; a < TA; ++a) u[a] = S[min((wf0 + 16 * a + li + rq) * DP + rm, lds_last)];
+        for (int a = 0; a < TA; ++a) u[a] = S[min(ubase[a] + lin, lds_last)];
         rm += 4;
+        lin += 4;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {   // D >= 1: at most 4 wraps, branch free
+        for (int w = 0; w < WRAPS; ++w) {   // D >= 1: at most 4 wraps, branch free
             const bool wrap = rm >= D;
             rm -= wrap ? D : 0;
-            rq += wrap ? 1 : 0;
+            lin += wrap ? DP - D : 0;
         }
     };
     auto step = [&](int ks, const cplx (&g)[NB], const cplx (&u)[TA]) {
-        const bool ok = 4 * ks + lk < n;
+        const bool ok = !TAIL || 4 * ks + lk < n;
         double ur[TA], ui[TA], gr[NB], gi[NB];
 #pragma unroll
         for (int a = 0; a < TA; ++a) {
@@ -1956,6 +1981,11 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, true, 2> : wpe_apply_kernel<apply_ta, 2, true, 2>;
     if (apply_3m && apply_nwv == 3)
         apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, true, 3> : wpe_apply_kernel<apply_ta, 2, true, 3>;
+    // the common case -- four or more channels, taps * D a multiple of 4: one carry per k-step,
+    // no row mask (GSS_APPLY_GENERIC=1: the general form)
+    if (apply_3m && apply_nwv == 4 && D >= 4 && n % 4 == 0 && getenv("GSS_APPLY_GENERIC") == nullptr)
+        apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, true, 4, 1, false>
+                           : wpe_apply_kernel<apply_ta, 2, true, 4, 1, false>;
     const size_t apply_lds = sizeof(cplx) * (size_t)(apply_frames + c + 2) * (D | 1);
     // frame phases packed into the N dimension (wpe_apply_packed_kernel): pick the number of
     // phases that minimises the MFMAs per frame, ceil(PH D / 16) (n + (PH - 1) D) / PH
