@@ -772,7 +772,7 @@ def test_kernel_variants_agree(gpu_ctx, D, monkeypatch):
                 # queue orders, block-wise accumulation)
                 {'GSS_MSTEP_CHUNKED': '1'}, {'GSS_MSTEP_SLOTS': '100'}, {'GSS_EM_UNFUSED': '1'},
                 {'GSS_CORR_PERSIST': '0'}, {'GSS_CORR_QBLOCK': '4'}, {'GSS_CORR_FMAJOR': '1'},
-                {'GSS_CORR_BLOCKED': '1'}):
+                {'GSS_CORR_BLOCKED': '1'}, {'GSS_CORR_TS': '3'}, {'GSS_APPLY_GENERIC': '1'}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         other, odet = run()
