@@ -785,6 +785,9 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_persist_kernel(
 // A non-positive pivot (exactly singular system, e.g. an all-zero channel) zeroes
 // that row, which reproduces the minimum-norm lstsq fallback of stable_solve
 // (pb_chime5/math/solve.py:95-114) for zero rows / columns.
+#ifndef GSS_EXP_UPD
+#define GSS_EXP_UPD 0
+#endif
 #ifndef GSS_UPD_PREFETCH
 #define GSS_UPD_PREFETCH 1     // k-steps of operands in flight beyond the next one (chol_update)
 #endif
@@ -979,6 +982,9 @@ __device__ inline void chol_update_tile(cplx *A, cplx *Z, int n, int D, int j0, 
     const int ncols = tl.is_p ? D : n;
 
     auto load_ops = [&](int ks, cplx (&a)[TM], cplx (&b)[TN]) {
+#if GSS_EXP_UPD == 1      // timing-only ablation: no operand loads after the first k-step
+        if (ks > 0) return;
+#endif
         const int kk = 4 * ks + lk;
         const bool kv = kk < nb;
 #pragma unroll
@@ -1050,9 +1056,13 @@ __device__ inline void chol_update_tile(cplx *A, cplx *Z, int n, int D, int j0, 
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
+#if GSS_EXP_UPD == 2      // timing-only ablation: no MFMAs
+                t1[a][b][0] += a_cur[a].x + b_cur[b].x + as[a] + bd[b];
+#else
                 t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[a].x, b_cur[b].x, t1[a][b], 0, 0, 0);
                 t2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[a].y, b_cur[b].y, t2[a][b], 0, 0, 0);
                 t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[a], bd[b], t3[a][b], 0, 0, 0);
+#endif
             }
         if (PREFETCH) {
 #pragma unroll
