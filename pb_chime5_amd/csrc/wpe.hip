@@ -1355,7 +1355,8 @@ __global__ __launch_bounds__(256, 3) void chol_backsolve_kernel(const cplx *__re
 // t2 = sum ui gi, t3 = sum (ur + ui)(gr - gi); re = t1 + t2, im = t3 - t1 + t2).
 // WRAPS: carries of the running (r / D, r % D) per k-step -- one is enough from D = 4 on (r
 // advances by 4), and every wrap is three VALU instructions that the MFMA pipe waits for.
-// TAIL: n is not a multiple of 4 (the last k-step's rows r >= n have to be masked).
+// TAIL: rows r >= n have to be masked -- n is not a multiple of 8 (the loop runs two k-steps per
+// trip, so an odd k-step count executes one k-step past the end).
 template <int TA, int NB, bool M3, int NWV = 4, int WRAPS = 4, bool TAIL = true>
 __global__ __launch_bounds__(64 * NWV) void wpe_apply_kernel(const cplx *__restrict__ Y,
                                                         const cplx *__restrict__ G, int F,
@@ -1991,11 +1992,18 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, true, 2> : wpe_apply_kernel<apply_ta, 2, true, 2>;
     if (apply_3m && apply_nwv == 3)
         apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, true, 3> : wpe_apply_kernel<apply_ta, 2, true, 3>;
-    // the common case -- four or more channels, taps * D a multiple of 4: one carry per k-step,
+    // the common case -- four or more channels: one carry per k-step; taps * D a multiple of 8:
     // no row mask (GSS_APPLY_GENERIC=1: the general form)
-    if (apply_3m && apply_nwv == 4 && D >= 4 && n % 4 == 0 && getenv("GSS_APPLY_GENERIC") == nullptr)
-        apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, true, 4, 1, false>
-                           : wpe_apply_kernel<apply_ta, 2, true, 4, 1, false>;
+    // (the k loop runs two k-steps per trip: without the row mask the k-step count must be
+    // even, i.e. 8 | taps * D -- 36 rows are 9 k-steps and the tenth would add clamped garbage)
+    if (apply_3m && apply_nwv == 4 && D >= 4 && getenv("GSS_APPLY_GENERIC") == nullptr) {
+        if (n % 8 == 0)
+            apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, true, 4, 1, false>
+                               : wpe_apply_kernel<apply_ta, 2, true, 4, 1, false>;
+        else
+            apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, true, 4, 1, true>
+                               : wpe_apply_kernel<apply_ta, 2, true, 4, 1, true>;
+    }
     const size_t apply_lds = sizeof(cplx) * (size_t)(apply_frames + c + 2) * (D | 1);
     // frame phases packed into the N dimension (wpe_apply_packed_kernel): pick the number of
     // phases that minimises the MFMAs per frame, ceil(PH D / 16) (n + (PH - 1) D) / PH

@@ -141,7 +141,12 @@ def _reverberant(rng, D, T, F, taps=6):
 
 @pytest.mark.parametrize('D,T,F,taps,delay,iters', [
     (4, 60, 9, 3, 2, 2), (2, 40, 5, 1, 0, 1), (5, 131, 7, 4, 3, 3), (24, 941, 2, 10, 2, 3),
-    (12, 500, 3, 10, 2, 2), (3, 60, 4, 10, 2, 1), (29, 700, 1, 10, 2, 1), (32, 300, 3, 2, 2, 2)])
+    (12, 500, 3, 10, 2, 2), (3, 60, 4, 10, 2, 1), (29, 700, 1, 10, 2, 1), (32, 300, 3, 2, 2, 2),
+    # taps * D = 36 / 100 / 44 / 60: an odd number of k-steps in the filter application (its k
+    # loop runs two per trip; the specialisation without a row mask must not be chosen), and
+    # taps * D = 72 / 200 with an even one
+    (12, 260, 3, 3, 2, 2), (10, 400, 2, 10, 1, 2), (11, 300, 2, 4, 2, 1), (20, 330, 2, 3, 2, 1),
+    (24, 330, 2, 3, 2, 2), (20, 450, 1, 10, 2, 1)])
 def test_wpe_matches_oracle(gpu_ctx, D, T, F, taps, delay, iters):
     from pb_chime5_amd import ops
     rng = np.random.default_rng(D * T)
