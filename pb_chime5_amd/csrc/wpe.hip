@@ -53,9 +53,32 @@ __global__ __launch_bounds__(POW_FRAMES) void wpe_power_kernel(const cplx *__res
         const int total = nfr * D;
         const cplx *src = Xf + t0 * D;
         __syncthreads();
-        for (int idx = tid; idx < total; idx += POW_FRAMES) {
-            const int fr = idx / D, d = idx - fr * D;
-            ps[fr * DP + d] = c_abs2(src[idx]);
+        // eight loads of a thread in flight before the first LDS store (one per trip was a
+        // chain of round trips: 513 workgroups x 256 threads x 16 bytes in flight are a
+        // quarter of what the memory system needs to stream), (frame, channel) of an element
+        // advanced without dividing: idx + 256 = (fr + 256 / D, d + 256 % D) with one carry
+        {
+            constexpr int LB = 8;
+            const int qf = POW_FRAMES / D, rf = POW_FRAMES - qf * D;
+            int fr = tid / D, d = tid - fr * D;
+            for (int base = tid; base < total; base += LB * POW_FRAMES) {
+                cplx v[LB];
+#pragma unroll
+                for (int j = 0; j < LB; ++j) {
+                    const int idx = base + j * POW_FRAMES;
+                    v[j] = idx < total ? src[idx] : c_make(0.0, 0.0);
+                }
+#pragma unroll
+                for (int j = 0; j < LB; ++j) {
+                    if (base + j * POW_FRAMES < total) ps[fr * DP + d] = c_abs2(v[j]);
+                    fr += qf;
+                    d += rf;
+                    if (d >= D) {
+                        d -= D;
+                        ++fr;
+                    }
+                }
+            }
         }
         __syncthreads();
         if (tid < nfr) {
