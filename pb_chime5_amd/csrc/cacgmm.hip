@@ -101,17 +101,44 @@ struct EmArgs {
 template <bool NORMALISE>
 __device__ __forceinline__ void load_tile(const cplx *Yf, int D, int64_t t0, int64_t c1, int tl,
                                           int g, cplx *ys, double *scratch) {
-    const int64_t t = t0 + tl;
-    double nrm = 0.0;
-    cplx v[8];   // D <= 32 -> at most 8 channels per group
+    // The 64 x D elements of the tile are one contiguous run of the (T, D) slab: consecutive
+    // threads load consecutive elements (a lane walking its own frame touched 64 cache lines
+    // per load instruction; em_prepare 0.073 -> 0.060 ms) and scatter them to ys[d][frame];
+    // (frame, channel) of element idx + 256 follows from that of idx with one carry.
+    const int tid = g * EM_TILE + tl;
+    const int nfr = (int)min((int64_t)EM_TILE, c1 - t0);
+    const int total = nfr * D;
+    const cplx *src = Yf + t0 * D;
+    const int qf = 256 / D, rf = 256 - qf * D;
+    cplx v[8];   // D <= 32 -> at most 8 elements per thread
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int d = g + 4 * j;
-        v[j] = c_make(0.0, 0.0);
-        if (d < D && t < c1) v[j] = Yf[t * D + d];
-        nrm += c_abs2(v[j]);
+        const int idx = tid + 256 * j;
+        v[j] = idx < total ? src[idx] : c_make(0.0, 0.0);
+    }
+    {
+        int fr = tid / D, d = tid - fr * D;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (tid + 256 * j < EM_TILE * D) ys[d * EM_TS + fr] = v[j];     // (zeros past the last frame)
+            fr += qf;
+            d += rf;
+            if (d >= D) {
+                d -= D;
+                ++fr;
+            }
+        }
     }
     if (NORMALISE) {
+        __syncthreads();
+        // per frame: the four groups' partial sums over d = g, g + 4, ... in that order, then
+        // the groups in order -- the summation order of the loader this one replaces
+        double nrm = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = g + 4 * j;
+            nrm += d < D ? c_abs2(ys[d * EM_TS + tl]) : 0.0;
+        }
         scratch[g * EM_TILE + tl] = nrm;
         __syncthreads();
         nrm = scratch[tl] + scratch[EM_TILE + tl] + scratch[2 * EM_TILE + tl] +
@@ -121,13 +148,10 @@ __device__ __forceinline__ void load_tile(const cplx *Yf, int D, int64_t t0, int
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int d = g + 4 * j;
-            if (d < D) ys[d * EM_TS + tl] = c_make(v[j].x / nrm, v[j].y / nrm);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int d = g + 4 * j;
-            if (d < D) ys[d * EM_TS + tl] = v[j];
+            if (d < D) {
+                const cplx y = ys[d * EM_TS + tl];
+                ys[d * EM_TS + tl] = c_make(y.x / nrm, y.y / nrm);
+            }
         }
     }
 }
