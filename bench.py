@@ -587,12 +587,35 @@ def main():
     dist = None
     coll_device = 'cpu'
     backend = None
+    coll_group = None
     if world > 1:
-        # RCCL when every rank has its own GPU (the contract's launch), gloo when ranks
-        # share devices; either way it only carries barriers and two scalars.
-        backend = os.environ.get('GSS_BENCH_BACKEND', 'gloo' if shared_devices else 'nccl')
-        dist = parallel.init(backend=backend)
-        coll_device = 'cuda' if backend == 'nccl' else 'cpu'
+        # The process group only carries barriers and a few scalars (no collective on the data
+        # path).  It is ALWAYS joined over gloo -- nothing of the run depends on RCCL coming
+        # up --, and when every rank has a GPU of its own (the contract's launch) the timing
+        # barriers and reductions go through an RCCL sub-group that is probed first: one
+        # all-reduce on the device; if it fails on any rank, every rank stays on gloo and the
+        # line says so (`rank_backend`, `rccl_ranks`).  GSS_BENCH_BACKEND=gloo|nccl forces one.
+        want = os.environ.get('GSS_BENCH_BACKEND', 'gloo' if shared_devices else 'nccl')
+        dist = parallel.init(backend='gloo')
+        backend = 'gloo'
+        if want == 'nccl':
+            ok = 1.0
+            try:
+                # (HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver only supports dmabuf IPC)
+                os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+                g = dist.new_group(backend='nccl')
+                probe = torch.ones(1, dtype=torch.float64, device='cuda')
+                dist.all_reduce(probe, group=g)
+                torch.cuda.synchronize()
+                ok = 1.0 if float(probe.item()) == world else 0.0
+            except Exception as e:           # noqa: BLE001 -- anything RCCL throws
+                print(f'bench.py: rank {rank}: RCCL sub-group not usable ({type(e).__name__}: '
+                      f'{str(e)[:200]}); staying on gloo', file=sys.stderr)
+                ok, g = 0.0, None
+            flag = torch.tensor([ok], dtype=torch.float64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) == 1.0:
+                coll_group, backend, coll_device = g, 'nccl', 'cuda'
 
     ctx = Context(device_index)
     _capi._DEFAULT_CTX[device_index] = ctx
@@ -601,6 +624,8 @@ def main():
         ctx.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
+            if coll_group is not None:
+                dist.barrier(group=coll_group)
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -608,14 +633,14 @@ def main():
         if dist is None:
             return float(x)
         t = torch.tensor([x], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=coll_group)
         return float(t.item())
 
     def sum_over_ranks(x):
         if dist is None:
             return float(x)
         t = torch.tensor([x], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=coll_group)
         return float(t.item())
 
     def gather_over_ranks(values):
@@ -624,7 +649,7 @@ def main():
             return [list(map(float, values))]
         t = torch.zeros((world, len(values)), dtype=torch.float64, device=coll_device)
         t[rank] = torch.tensor(list(values), dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=coll_group)
         return t.cpu().tolist()
 
     params = ops.make_params(wpe=True, wpe_taps=WORKLOAD['wpe_taps'],

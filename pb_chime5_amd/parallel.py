@@ -59,9 +59,9 @@ def _dist():
 
 def init(backend=None):
     """Join the process group of the launcher.  Only host-side rendezvous, barriers and
-    the work counter use it, so gloo always suffices; nccl (= RCCL) is picked when every
-    local rank has a GPU of its own, gloo on CPU-only hosts and when ranks share GPUs
-    (a node with fewer GPUs than ranks: device = LOCAL_RANK % device count)."""
+    the work counter use it, so gloo always suffices and is the default; nccl (= RCCL) on
+    request (`backend='nccl'` / GSS_DIST_BACKEND=nccl).  On a node with fewer GPUs than ranks
+    the ranks share devices (device = LOCAL_RANK % device count)."""
     if world_size() == 1:
         return None
     import torch
@@ -70,10 +70,11 @@ def init(backend=None):
         if backend is None:
             backend = os.environ.get('GSS_DIST_BACKEND')
         if backend is None:
-            local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world_size()))
-            n_gpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
-            backend = 'nccl' if n_gpu >= local_world else 'gloo'
+            # gloo: rendezvous, barriers and the work counter are host-side; a session must
+            # not depend on RCCL coming up on the node (GSS_DIST_BACKEND=nccl selects it)
+            backend = 'gloo'
         if backend == 'nccl':
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
             torch.cuda.set_device(device_index())
         dist.init_process_group(backend=backend)
     return dist
