@@ -555,6 +555,9 @@ def parse_args():
 
 def main():
     args = parse_args()
+    # before anything initialises ROCr (the host driver only supports dmabuf IPC; the driver's
+    # environment exports it, a hand-made one may not)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world == 1 and args.gpus > 1:
         # plain `python bench.py --gpus N`: be our own mpiexec
@@ -570,6 +573,7 @@ def main():
     os.dup2(2, 1)
 
     def emit(line):
+        line.setdefault('placement', placement)
         os.write(result_fd, (json.dumps(line) + '\n').encode())
 
     import torch
@@ -598,24 +602,49 @@ def main():
         want = os.environ.get('GSS_BENCH_BACKEND', 'gloo' if shared_devices else 'nccl')
         dist = parallel.init(backend='gloo')
         backend = 'gloo'
-        if want == 'nccl':
-            ok = 1.0
+
+        def all_agree(flag):
+            t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return float(t.item()) == 1.0
+        # Every step of the probe is agreed over gloo BEFORE the next one: a rank that fails
+        # alone must not leave the others inside an RCCL call (communicator set-up needs
+        # every rank).  What remains is a failure inside the first all-reduce itself: the
+        # probe group has a short timeout and waits in blocking mode, so that shows up as an
+        # exception on every rank instead of a hang.
+        if all_agree(want == 'nccl'):
+            g = None
             try:
-                # (HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver only supports dmabuf IPC)
-                os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-                g = dist.new_group(backend='nccl')
-                probe = torch.ones(1, dtype=torch.float64, device='cuda')
-                dist.all_reduce(probe, group=g)
-                torch.cuda.synchronize()
-                ok = 1.0 if float(probe.item()) == world else 0.0
+                from datetime import timedelta
+                os.environ.setdefault('TORCH_NCCL_BLOCKING_WAIT', '1')
+                g = dist.new_group(backend='nccl', timeout=timedelta(seconds=60))
             except Exception as e:           # noqa: BLE001 -- anything RCCL throws
-                print(f'bench.py: rank {rank}: RCCL sub-group not usable ({type(e).__name__}: '
-                      f'{str(e)[:200]}); staying on gloo', file=sys.stderr)
-                ok, g = 0.0, None
-            flag = torch.tensor([ok], dtype=torch.float64)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if float(flag.item()) == 1.0:
+                print(f'bench.py: rank {rank}: no RCCL sub-group ({type(e).__name__}: '
+                      f'{str(e)[:200]})', file=sys.stderr)
+            ok = all_agree(g is not None)
+            if ok:
+                try:
+                    probe = torch.ones(1, dtype=torch.float64, device='cuda')
+                    dist.all_reduce(probe, group=g)
+                    torch.cuda.synchronize()
+                    ok = float(probe.item()) == world
+                except Exception as e:       # noqa: BLE001
+                    print(f'bench.py: rank {rank}: RCCL probe failed ({type(e).__name__}: '
+                          f'{str(e)[:200]}); staying on gloo', file=sys.stderr)
+                    ok = False
+                ok = all_agree(ok)
+            if ok:
                 coll_group, backend, coll_device = g, 'nccl', 'cuda'
+
+    # threads started from here on (loaders, feeder, writer, the CPU baseline's pool excepted:
+    # it resets its mask) run on the socket of this rank's GPU
+    full_mask = os.sched_getaffinity(0)
+    affinity = parallel.bind_to_gpu_numa(device_index)
+    placement = [dict(rank=rank, device=device_index, **affinity)]
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, placement[0])
+        placement = gathered
 
     ctx = Context(device_index)
     _capi._DEFAULT_CTX[device_index] = ctx
@@ -1076,6 +1105,11 @@ def main():
             'config4_standin': standin,
         }
         if args.gpus == 1 and extras and not args.no_cpu_baseline:
+            # the reference's mpiexec workers are not tied to the GPU's socket: all host cores
+            try:
+                os.sched_setaffinity(0, full_mask)
+            except OSError:
+                pass
             line['cpu_baseline'] = cpu_baseline(utt, args.cpu_bins, args.cpu_workers)
             line['speedup_vs_cpu_all_cores'] = line['value'] / line['cpu_baseline']['value']
         emit(line)

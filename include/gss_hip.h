@@ -65,9 +65,9 @@ typedef enum {
 
 /* ABI revision of this header.  Bumped whenever an entry point changes its argument list
  * or a struct its layout (round 2 added `psd_context` to gss_wpe and `wpe_psd_context` to
- * gss_params: revision 2; rounds 3 and 4 added entry points only: revisions 3, 4.  A binder compares
+ * gss_params: revision 2; rounds 3, 4 and 5 added entry points only: revisions 3, 4, 5).  A binder compares
  * gss_abi_version() with the GSS_ABI_VERSION it was written against before any other call. */
-#define GSS_ABI_VERSION 4
+#define GSS_ABI_VERSION 5
 int gss_abi_version(void);
 
 /* ---- context ----------------------------------------------------------- */
@@ -75,6 +75,10 @@ int gss_abi_version(void);
  * LOCAL_RANK % gss_device_count() (pb_chime5_amd.parallel, replacing dlp_mpi's
  * rank handling at core.py:363-381). */
 int gss_device_count(void);
+/* PCI address of a device ("0000:c1:00.0", NUL-terminated, `len` >= 16 bytes): the host side
+ * reads /sys/bus/pci/devices/<address>/{numa_node,local_cpulist} to run a rank's threads on
+ * the socket its GPU hangs off (the reference leaves placement to mpiexec, README.md:108-111). */
+int gss_device_pci_bus_id(int device_id, char *buf, int len);
 int gss_create(int device_id, gss_ctx **ctx);
 int gss_destroy(gss_ctx *ctx);
 const char *gss_last_error(gss_ctx *ctx);
@@ -96,8 +100,10 @@ int gss_memset(gss_ctx *ctx, void *dst_dev, int value, size_t bytes);
  * driver reads WAV samples straight into such a block (replaces the reference's soundfile
  * read + float64 conversion + np.array stacking, io/audioread.py:34-226, core.py:427-470).
  * gss_host_malloc / gss_host_free touch no context state (the context only names the GPU
- * and receives the error message) and may be called from any thread; gss_host_free does not
- * synchronise: no copy from / to the block may be in flight. */
+ * and receives the error message) and may be called from any thread.  gss_host_free does not
+ * wait for the context's stream itself -- no copy from / to the block may be in flight -- but
+ * hipHostFree underneath waits for the WHOLE device on ROCm: free page-locked blocks when a
+ * session ends, not between utterances (the session driver parks outgrown blocks until then). */
 int gss_host_malloc(gss_ctx *ctx, size_t bytes, void **host_ptr);
 int gss_host_free(gss_ctx *ctx, void *host_ptr);
 int gss_memcpy_h2d_async(gss_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);

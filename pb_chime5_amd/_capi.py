@@ -18,7 +18,7 @@ GSS_ERR_INVALID = -1
 GSS_ERR_HIP = -2
 GSS_ERR_NOMEM = -3
 GSS_ERR_UNSUPPORTED = -4
-GSS_ABI_VERSION = 4       # include/gss_hip.h revision these prototypes are written against
+GSS_ABI_VERSION = 5       # include/gss_hip.h revision these prototypes are written against
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -42,6 +42,7 @@ class GssDebugTaps(ctypes.Structure):
 # name -> (restype, argtypes); every symbol include/gss_hip.h declares
 SIGNATURES = {
     'gss_device_count': (c_int, []),
+    'gss_device_pci_bus_id': (c_int, [c_int, ctypes.c_char_p, c_int]),
     'gss_create': (c_int, [c_int, ctypes.POINTER(c_void_p)]),
     'gss_destroy': (c_int, [c_void_p]),
     'gss_last_error': (ctypes.c_char_p, [c_void_p]),
@@ -354,6 +355,15 @@ _DEFAULT_CTX = {}
 
 def device_count():
     return int(load_library().gss_device_count())
+
+
+def device_pci_bus_id(device_id):
+    """'0000:c1:00.0' -- the key of the device's sysfs entry (NUMA node, local CPUs)."""
+    buf = ctypes.create_string_buffer(32)
+    rc = load_library().gss_device_pci_bus_id(int(device_id), buf, len(buf))
+    if rc != 0:
+        raise GssError(f'gss_device_pci_bus_id({device_id}) failed with status {rc}')
+    return buf.value.decode()
 
 
 def default_device():

@@ -75,9 +75,15 @@ class Activity:
     path: str = None
     store: dict = None
 
+    # sessions kept at a time: the reference keeps one (lru_cache(1), core.py:104); a rank of a
+    # multi-session run ('dev' = S02 + S09, longest first) alternates between a few
+    _CACHE_SESSIONS = 4
+
     def __post_init__(self):
+        import threading
         self._db = None
-        self._cached = (None, None)
+        self._cache = {}                 # session_id -> tracks, insertion-ordered (LRU)
+        self._cache_lock = threading.Lock()
 
     @property
     def db(self):
@@ -86,17 +92,31 @@ class Activity:
             self._db = Chime5(self.database_path or default_database_path())
         return self._db
 
+    def _annotation_activity(self, session_id):
+        from pb_chime5_amd.activity import get_activity
+        return get_activity(
+            iterator=self.db.get_datasets(session_id), perspective='array',
+            garbage_class=self.garbage_class, dtype=bool,
+            use_ArrayIntervall=True)[session_id]
+
+    def _cached_annotation(self, session_id):
+        """Called from every loader thread of a session (`Enhancer._prepare_into`): the look-up,
+        the computation and the hand-out of ONE session's tracks happen under a lock, and the
+        caller gets the object it asked for, never "whatever the cache holds now"."""
+        with self._cache_lock:
+            tracks = self._cache.pop(session_id, None)
+            if tracks is None:
+                tracks = self._annotation_activity(session_id)
+                while len(self._cache) >= self._CACHE_SESSIONS:
+                    self._cache.pop(next(iter(self._cache)))
+            self._cache[session_id] = tracks      # most recently used last
+            return tracks
+
     def __getitem__(self, session_id):
         if self.store is not None:
             return self.store[session_id]
         if self.type == 'annotation':
-            if self._cached[0] != session_id:
-                from pb_chime5_amd.activity import get_activity
-                self._cached = (session_id, get_activity(
-                    iterator=self.db.get_datasets(session_id), perspective='array',
-                    garbage_class=self.garbage_class, dtype=bool,
-                    use_ArrayIntervall=True)[session_id])
-            return self._cached[1]
+            return self._cached_annotation(session_id)
         if self.type == 'path':
             with open(Path(self.path) / f'{session_id}.pkl', 'rb') as fd:
                 return _ReferenceUnpickler(fd).load()

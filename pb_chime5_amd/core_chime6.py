@@ -36,16 +36,12 @@ class Activity(core.Activity):
             self._db = Chime5(self.database_path or default_database_path_chime6())
         return self._db
 
-    def __getitem__(self, session_id):
-        if self.store is None and self.type == 'annotation':
-            if self._cached[0] != session_id:
-                from pb_chime5_amd.activity import get_activity_chime6
-                self._cached = (session_id, get_activity_chime6(
-                    iterator=self.db.get_datasets(session_id),
-                    garbage_class=self.garbage_class, dtype=bool,
-                    use_ArrayIntervall=True)[session_id])
-            return self._cached[1]
-        return super().__getitem__(session_id)
+    def _annotation_activity(self, session_id):
+        from pb_chime5_amd.activity import get_activity_chime6
+        return get_activity_chime6(
+            iterator=self.db.get_datasets(session_id),
+            garbage_class=self.garbage_class, dtype=bool,
+            use_ArrayIntervall=True)[session_id]
 
 
 @dataclass

@@ -41,6 +41,15 @@ extern "C" int gss_device_count(void) {
     return count;
 }
 
+extern "C" int gss_device_pci_bus_id(int device_id, char *buf, int len) {
+    if (!buf || len < 16) return GSS_ERR_INVALID;
+    buf[0] = 0;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device_id < 0 || device_id >= count)
+        return GSS_ERR_INVALID;
+    return hipDeviceGetPCIBusId(buf, len, device_id) == hipSuccess ? GSS_OK : GSS_ERR_HIP;
+}
+
 extern "C" int gss_create(int device_id, gss_ctx **out) {
     if (!out) return GSS_ERR_INVALID;
     *out = nullptr;
@@ -182,9 +191,9 @@ extern "C" int gss_host_malloc(gss_ctx *ctx, size_t bytes, void **host_ptr) {
 extern "C" int gss_host_free(gss_ctx *ctx, void *host_ptr) {
     if (!ctx) return GSS_ERR_INVALID;
     if (!host_ptr) return GSS_OK;
-    // no stream synchronisation here (unlike gss_dev_free): loader threads resize their
-    // staging blocks while the context's owner thread is enqueueing; the caller guarantees
-    // that no copy from / to the block is still in flight
+    // no stream synchronisation of our own (unlike gss_dev_free); the caller guarantees that
+    // no copy from / to the block is still in flight.  hipHostFree itself waits for the whole
+    // device, which is why the session driver only frees at the end of a session
     GSS_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     GSS_HIP_CHECK(ctx, hipHostFree(host_ptr));
     return GSS_OK;

@@ -27,14 +27,15 @@ import numpy as np
 
 def _load_one(path, start=None, stop=None, dtype=np.float64):
     import os
-    from pb_chime5_amd.io.wav_slices import parse_wav_header
+    from pb_chime5_amd.io.wav_slices import WavSliceReader, parse_wav_header
     fd = os.open(os.fspath(path), os.O_RDONLY)
     try:
         offset, total, channels, _ = parse_wav_header(fd, path)   # NotImplementedError: not PCM16
         start = 0 if start is None else min(int(start), total)
         stop = total if stop is None else min(int(stop), total)
         count = max(stop - start, 0)
-        raw = os.pread(fd, 2 * channels * count, offset + 2 * channels * start)
+        raw = bytearray(2 * channels * count)
+        WavSliceReader._pread_all(fd, memoryview(raw), offset + 2 * channels * start)
     finally:
         os.close(fd)
     data = np.frombuffer(raw, dtype='<i2')

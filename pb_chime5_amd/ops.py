@@ -382,23 +382,29 @@ class HostStaging:
         self.ctx = ctx
         self.block = None
         self.obs = self.act = None
+        self._retired = []
 
     def shape(self, D, N, K, N_act):
         off = (2 * D * N + 255) // 256 * 256
         need = off + K * N_act
         if self.block is None or self.block.nbytes < need:
+            # hipHostFree waits for the whole device (every stream of every utterance in
+            # flight): an outgrown block is parked until free(), and blocks at least double, so
+            # a session parks a handful of them
+            have = 0
             if self.block is not None:
-                self.block.free()
-            self.block = self.ctx.pinned(int(need * 1.25) + 4096)
+                self._retired.append(self.block)
+                have = self.block.nbytes
+            self.block = self.ctx.pinned(max(int(need * 1.25) + 4096, 2 * have))
         self.obs = self.block.view((D, N), np.int16, 0)
         self.act = self.block.view((K, N_act), np.uint8, off)
         return self.obs, self.act
 
     def free(self):
         self.obs = self.act = None
-        if self.block is not None:
-            self.block.free()
-            self.block = None
+        for block in self._retired + ([self.block] if self.block is not None else []):
+            block.free()
+        self.block, self._retired = None, []
 
 
 class UtterancePipeline:
@@ -439,6 +445,7 @@ class UtterancePipeline:
         for st in self._all_staging:
             self._staging.put(st)
         self._out_host = [None for _ in self.slots]
+        self._out_retired = []
 
     def __len__(self):
         return len(self._pending)
@@ -507,9 +514,12 @@ class UtterancePipeline:
         out_d = self._buffer(slot, 'out', 8 * max(n_out, 1))
         out_h = self._out_host[slot]
         if out_h is None or out_h.nbytes < 8 * (b - a):
-            if out_h is not None:
-                out_h.free()
-            out_h = self._out_host[slot] = ctx.pinned(int(8 * (b - a) * 1.25) + 4096)
+            have = 0
+            if out_h is not None:            # parked until close(), see HostStaging.shape
+                self._out_retired.append(out_h)
+                have = out_h.nbytes
+            out_h = self._out_host[slot] = ctx.pinned(
+                max(int(8 * (b - a) * 1.25) + 4096, 2 * have))
         out_view = out_h.view((b - a,), np.float64)
         ctx.upload_async(obs_d, obs)
         ctx.upload_async(act_d, act)
@@ -559,12 +569,14 @@ class UtterancePipeline:
                     pass
         finally:
             self._bufs = [dict() for _ in self.slots]
-            for block in self._all_staging + [h for h in self._out_host if h is not None]:
+            for block in (self._all_staging + self._out_retired
+                          + [h for h in self._out_host if h is not None]):
                 try:
                     block.free()
                 except Exception:
                     pass
             self._all_staging, self._out_host = [], [None for _ in self.slots]
+            self._out_retired = []
             for c in self.slots[1:]:
                 try:
                     c.close()

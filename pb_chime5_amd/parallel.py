@@ -6,23 +6,85 @@ independent, so there is no data-path collective and no RCCL: one process per GP
 (RANK / LOCAL_RANK / WORLD_SIZE from the launcher, e.g. torch.distributed.run),
 each pulling utterance indices either
 
-* dynamically from a shared counter kept in the launcher's TCP store (the analogue
-  of dlp_mpi's master handing out indices on request), or
-* statically (``index % world == rank`` over a longest-first ordering) when no
-  store is reachable.
+* dynamically from a shared counter (the analogue of dlp_mpi's master handing out indices
+  on request): a few int64 slots in a file under /dev/shm when the ranks were started by
+  `launch_local` (all node-local: no torch import, a rank is up in well under a second), or
+  a key in the launcher's TCP store under torch.distributed.run (gloo), or
+* statically (``index % world == rank`` over a longest-first ordering) when neither is
+  reachable.
 
 Single-process runs degrade to a plain loop (``allow_single_worker=True`` upstream).
 
 ``launch_local(n, argv)`` is the stand-in for ``mpiexec -np n`` (reference
 README.md:108-111): it starts n copies of a command on this node, one per GPU, with
 the rendezvous variables torch.distributed.run would set.
+
+Every rank binds itself (and the loader / feeder / writer threads it starts later) to the
+CPUs of its GPU's NUMA node (`bind_to_gpu_numa`): page-locked staging memory is then
+allocated on the socket the GPU hangs off.
 """
 import os
 import socket
 import subprocess
 import sys
 
-_STATE = {'store': None, 'epoch': 0}
+_STATE = {'store': None, 'epoch': 0, 'local': None, 'affinity': None}
+
+
+class LocalGroup:
+    """Counters and a barrier for the ranks of ONE node, in a file the launcher created
+    (GSS_LOCAL_GROUP): SLOTS int64 values, mapped shared, changed under flock().  Slot 0 is
+    the barrier's arrival counter (it only grows: the g-th barrier is passed once it reached
+    g * world), slot e the hand-out counter of the e-th `split_managed` of the run."""
+    SLOTS = 4096
+
+    def __init__(self, path, world):
+        import mmap
+        import threading
+        import numpy as np
+        self.world = world
+        self.fd = os.open(path, os.O_RDWR)
+        self._mm = mmap.mmap(self.fd, 8 * self.SLOTS)
+        self._v = np.frombuffer(self._mm, dtype=np.int64)
+        self._thread_lock = threading.Lock()       # flock() does not exclude threads of one fd
+        self._generation = 0
+
+    @classmethod
+    def create(cls, directory=None):
+        import tempfile
+        if directory is None:
+            directory = '/dev/shm' if os.path.isdir('/dev/shm') else None
+        fd, path = tempfile.mkstemp(prefix='gss_group_', dir=directory)
+        os.ftruncate(fd, 8 * cls.SLOTS)
+        os.close(fd)
+        return path
+
+    def add(self, slot, n=1):
+        import fcntl
+        with self._thread_lock:
+            fcntl.flock(self.fd, fcntl.LOCK_EX)
+            try:
+                value = int(self._v[slot]) + n
+                self._v[slot] = value
+            finally:
+                fcntl.flock(self.fd, fcntl.LOCK_UN)
+        return value
+
+    def barrier(self, poll=0.0005):
+        import time
+        self._generation += 1
+        target = self._generation * self.world
+        self.add(0, 1)
+        while int(self._v[0]) < target:
+            time.sleep(poll)
+
+    def close(self):
+        self._v = None
+        try:
+            self._mm.close()
+        except BufferError:
+            pass
+        os.close(self.fd)
 
 
 def rank():
@@ -49,8 +111,8 @@ def is_master():
 
 
 def _dist():
-    if world_size() == 1:
-        return None
+    if world_size() == 1 or 'torch.distributed' not in sys.modules:
+        return None          # (a process group nobody imported torch for cannot be up)
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized():
         return None
@@ -64,6 +126,9 @@ def init(backend=None):
     the ranks share devices (device = LOCAL_RANK % device count)."""
     if world_size() == 1:
         return None
+    bind_to_gpu_numa()
+    if backend is None and not os.environ.get('GSS_DIST_BACKEND') and _local_group() is not None:
+        return None                       # node-local ranks of launch_local: no process group
     import torch
     import torch.distributed as dist
     if not dist.is_initialized():
@@ -80,10 +145,23 @@ def init(backend=None):
     return dist
 
 
+def _local_group():
+    """The launcher's counter file, if this rank was started by `launch_local`."""
+    if _STATE['local'] is None:
+        path = os.environ.get('GSS_LOCAL_GROUP')
+        try:
+            _STATE['local'] = LocalGroup(path, world_size()) if path and world_size() > 1 else False
+        except OSError:
+            _STATE['local'] = False
+    return _STATE['local'] or None
+
+
 def barrier():
     dist = _dist()
     if dist is not None:
         dist.barrier()
+    elif _local_group() is not None:
+        _local_group().barrier()
 
 
 def _store():
@@ -121,18 +199,102 @@ def split_managed(sequence, costs=None, dynamic=True):
     if costs is not None:
         order.sort(key=lambda i: (-costs[i], i))
     store = _store() if dynamic else None
-    if store is None:
+    local = _local_group() if dynamic and store is None and _dist() is None else None
+    if store is None and local is None:
         for i in order[rank()::world]:
             yield items[i]
         return
     _STATE['epoch'] += 1
-    key = f'pb_chime5_amd/next/{_STATE["epoch"]}'
+    if store is not None:
+        key = f'pb_chime5_amd/next/{_STATE["epoch"]}'
+
+        def take():
+            return store.add(key, 1) - 1
+    else:
+        slot = _STATE['epoch']
+        assert slot < LocalGroup.SLOTS, 'more split_managed() calls than counter slots'
+
+        def take():
+            return local.add(slot, 1) - 1
     while True:
-        pos = store.add(key, 1) - 1
+        pos = take()
         if pos >= n:
             break
         yield items[order[pos]]
     barrier()
+
+
+# ------------------------------------------------------------------ CPU placement
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        a, _, b = part.partition('-')
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def _format_cpulist(cpus):
+    cpus = sorted(cpus)
+    runs, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        runs.append(str(cpus[i]) if i == j else f'{cpus[i]}-{cpus[j]}')
+        i = j + 1
+    return ','.join(runs)
+
+
+def gpu_numa_cpus(device, sysfs='/sys/bus/pci/devices'):
+    """(NUMA node, CPUs local to it) of a GPU, from the PCI device's sysfs entry
+    (`numa_node`, `local_cpulist`); (None, None) where the kernel does not say (one node,
+    a VM without topology, no sysfs)."""
+    from pb_chime5_amd import _capi
+    try:
+        bus_id = _capi.device_pci_bus_id(device).lower()
+        base = os.path.join(sysfs, bus_id)
+        with open(os.path.join(base, 'numa_node')) as fd:
+            node = int(fd.read())
+        with open(os.path.join(base, 'local_cpulist')) as fd:
+            cpus = _parse_cpulist(fd.read())
+    except Exception:            # noqa: BLE001 -- placement is an optimisation, never an error
+        return None, None
+    if node < 0 or not cpus:
+        return None, None
+    return node, cpus
+
+
+def bind_to_gpu_numa(device=None, force=False):
+    """Restrict the calling thread -- call it from the main thread before any worker thread
+    exists: they inherit the mask -- to the CPUs of its GPU's NUMA node (intersected with the
+    CPUs the process may use at all).  Eight ranks x (3 loaders + feeder + writer) threads
+    floating over two sockets put page-locked staging blocks on the far socket: H2D / D2H
+    through the inter-socket link.  GSS_NUMA_BIND=0 switches it off.  Returns (and keeps for
+    `affinity_info`) what was done; never raises."""
+    if _STATE['affinity'] is not None and not force:
+        return _STATE['affinity']
+    info = {'bound': False, 'numa_node': None, 'cpus': None}
+    try:
+        allowed = os.sched_getaffinity(0)
+        info['cpus'] = _format_cpulist(allowed)
+        if os.environ.get('GSS_NUMA_BIND', '1') != '0':
+            node, cpus = gpu_numa_cpus(device_index() if device is None else device)
+            info['numa_node'] = node
+            if cpus is not None and (allowed & cpus) and (allowed & cpus) != allowed:
+                os.sched_setaffinity(0, allowed & cpus)
+                info['bound'] = True
+                info['cpus'] = _format_cpulist(allowed & cpus)
+    except Exception as e:       # noqa: BLE001
+        info['error'] = f'{type(e).__name__}: {e}'
+    _STATE['affinity'] = info
+    return info
+
+
+def affinity_info():
+    """What `bind_to_gpu_numa` did in this rank ({'bound', 'numa_node', 'cpus'})."""
+    return _STATE['affinity'] or {'bound': False, 'numa_node': None, 'cpus': None}
 
 
 def free_port():
@@ -150,12 +312,26 @@ def launch_local(nprocs, argv, extra_env=None, timeout=None):
     by PID), else 0."""
     port = free_port()
     procs = []
-    for r in range(nprocs):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nprocs),
-                   LOCAL_WORLD_SIZE=str(nprocs), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-        env.update(extra_env or {})
-        procs.append(subprocess.Popen(list(argv), env=env,
-                                      stdout=None if r == 0 else sys.stderr))
+    group_file = LocalGroup.create()
+    try:
+        for r in range(nprocs):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nprocs),
+                       LOCAL_WORLD_SIZE=str(nprocs), MASTER_ADDR='127.0.0.1',
+                       MASTER_PORT=str(port), GSS_LOCAL_GROUP=group_file)
+            # the driver's environment has it; a hand-made one may not (dmabuf IPC only)
+            env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            env.update(extra_env or {})
+            procs.append(subprocess.Popen(list(argv), env=env,
+                                          stdout=None if r == 0 else sys.stderr))
+        return _wait_all(procs, timeout)
+    finally:
+        try:
+            os.unlink(group_file)
+        except OSError:
+            pass
+
+
+def _wait_all(procs, timeout):
     import time
     deadline = None if timeout is None else time.monotonic() + timeout
     status = 0

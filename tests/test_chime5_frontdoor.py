@@ -409,3 +409,42 @@ def test_activity_path_loads_pickles_written_by_the_reference(tmp_path):
     # and what this package pickles loads again (same protocol both ways)
     again = pickle.loads(pickle.dumps(act['U01']['P05']))
     assert again.normalized_intervals == act['U01']['P05'].normalized_intervals
+
+
+def test_activity_cache_hands_every_thread_the_session_it_asked_for():
+    """`Activity.__getitem__` is called from every loader thread of a session; a rank of a
+    multi-session run sees its sessions interleaved (the one-entry cache could
+    return another thread's session)."""
+    import threading
+    import time
+    from pb_chime5_amd.core import Activity
+
+    computed = []
+
+    class Slow(Activity):
+        def _annotation_activity(self, session_id):
+            computed.append(session_id)
+            time.sleep(0.002)
+            return {'session': session_id}
+
+    act = Slow()
+    errors = []
+
+    def work(seed):
+        rng = np.random.default_rng(seed)
+        try:
+            for _ in range(150):
+                sid = f'S{int(rng.integers(0, 3)):02d}'
+                assert act[sid]['session'] == sid
+        except Exception as e:       # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(s,)) for s in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert sorted(computed) == ['S00', 'S01', 'S02']          # once each, not once per switch
+    for sid in ('S03', 'S04', 'S05', 'S06'):                   # bounded
+        act[sid]
+    assert len(act._cache) == Activity._CACHE_SESSIONS and 'S00' not in act._cache

