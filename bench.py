@@ -433,6 +433,44 @@ def run_session(pipe, indices, get_item, clock=None):
     return count
 
 
+def other_workload(name, synthetic, ops):
+    """(utterance, params, description) of the BASELINE shapes that are not the headline; the
+    same scenes as the `configs` table of the default line."""
+    sr = SR
+    n3 = 554490                          # synthetic.config3_item(0): 4.66 s core + 2 x 15 s
+    iv3 = [(240000, n3 - 240000), (100000, 400000), (50000, 250000), (300000, 520000)]
+    meta = dict(WORKLOAD, name=name, steps=5)
+    params = ops.make_params(wpe=True, wpe_taps=WORKLOAD['wpe_taps'], wpe_delay=WORKLOAD['wpe_delay'],
+                             wpe_iterations=WORKLOAD['wpe_iterations'],
+                             bss_iterations=WORKLOAD['bss_iterations'],
+                             bss_iterations_post=WORKLOAD['bss_iterations_post'])
+    if name == '3i':
+        utt = synthetic.make_utterance(1000, 24, n3, iv3, start_context=240000, end_context=240000,
+                                       rir_taps=1024, noise=3e-2, fast=True)
+        meta['description'] = ('one dev-shaped item of BASELINE.json configs[2]: 24 ch, 34.7 s incl. '
+                               '2 x 15 s context, otherwise as configs[1]; inputs resident in HBM')
+    elif name == '1a':
+        utt = synthetic.make_utterance(1001, 4, n3, iv3, start_context=240000, end_context=240000,
+                                       rir_taps=1024, noise=3e-2, fast=True)
+        meta.update(num_channels=4, steps=20)
+        meta['description'] = ('the reference default multiarray=False (core.py:572-575): one array '
+                               '(4 ch) of a dev-shaped item, 34.7 s incl. 2 x 15 s context, WPE taps=10, '
+                               '20 EM iterations, MVDR-Souden + BAN; inputs resident in HBM')
+    elif name == '5':
+        iv5 = [(50 * sr, 70 * sr), (10 * sr, 60 * sr), (40 * sr, 100 * sr), (65 * sr, 115 * sr)]
+        utt = synthetic.make_utterance(5, 12, 120 * sr, iv5, start_context=50 * sr,
+                                       end_context=50 * sr, fast=True)
+        params = ops.make_params(wpe=True, wpe_taps=10, wpe_delay=2, wpe_iterations=3,
+                                 bss_iterations=40, bss_iterations_post=1, bf='gev_ban')
+        meta.update(num_channels=12, seconds=120.0, bss_iterations=40, steps=5)
+        meta['description'] = ('BASELINE.json configs[4]: 120 s RTTM-style segment, 12 ch '
+                               '(outer_array_mics of 6 arrays), WPE taps=10 delay=2 iters=3, 40 EM '
+                               'iterations + predict, GEV + BAN; inputs resident in HBM')
+    else:
+        raise ValueError(name)
+    return utt, params, meta
+
+
 def time_resident(ctx, ops, utt, params, steps, warmup=1):
     """ms per utterance, one stream, inputs resident in HBM."""
     ops._prepare_windows(ctx, params.stft_size, params.stft_shift)
@@ -547,6 +585,12 @@ def parse_args():
     ap.add_argument('--inflight', type=int, default=2)
     ap.add_argument('--static', action='store_true', help='config 3: static instead of dynamic sharding')
     ap.add_argument('--only-headline', action='store_true')
+    ap.add_argument('--workload', default='2', choices=('2', '5', '3i', '1a'),
+                    help="what the headline section times (anything but '2' implies "
+                         "--only-headline): 2 = BASELINE configs[1]; 5 = configs[4] (12 ch, 120 s, "
+                         "40 iterations, GEV+BAN); 3i = one dev-shaped item of configs[2] (24 ch, "
+                         "34.7 s); 1a = the same item on one array (4 ch, the reference default "
+                         "multiarray=False).  The profiles of those shapes are taken with it.")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-bins', type=int, default=24)
     ap.add_argument('--cpu-workers', type=int, default=None)
@@ -890,15 +934,28 @@ def main():
         return
 
     # ------------------------------------------------------------------ config 2 headline
-    steps = args.steps or 20
-    utt = synthetic.config2(seed=2 + rank, num_channels=WORKLOAD['num_channels'],
-                            seconds=WORKLOAD['seconds'],
-                            num_speakers=WORKLOAD['num_speakers'])
+    workload = dict(WORKLOAD, name='2', description=(
+        'BASELINE.json configs[1]: synthetic 24-mic (6 arrays x 4) 15 s '
+        'utterance, 4 speakers + noise class, WPE taps=10 delay=2 iters=3, '
+        '20 EM iterations + predict, MVDR-Souden + BAN; inputs resident in HBM'))
+    if args.workload == '2':
+        steps = args.steps or 20
+        utt = synthetic.config2(seed=2 + rank, num_channels=WORKLOAD['num_channels'],
+                                seconds=WORKLOAD['seconds'],
+                                num_speakers=WORKLOAD['num_speakers'])
+    else:
+        # the other BASELINE shapes through the same timed section (their rocprofv3 passes are
+        # taken with this command: one stream, one shape, back-to-back launches)
+        args.only_headline = True
+        utt, params, workload = other_workload(args.workload, synthetic, ops)
+        ops._prepare_windows(ctx, params.stft_size, params.stft_shift)
+        steps = args.steps or workload['steps']
     ctx_samples = utt.ex['start_orig']['original']
+    end_samples = utt.ex['end']['original'] - utt.ex['end_orig']['original']
     resident = ops.ResidentUtterance(ctx, utt.obs, utt.activity_array, params)
 
     def step():
-        resident.enqueue(utt.target_index, ctx_samples, ctx_samples)
+        resident.enqueue(utt.target_index, ctx_samples, end_samples)
 
     for _ in range(args.warmup):
         step()
@@ -1038,7 +1095,7 @@ def main():
     standin = config4s_session() if extras and not args.no_config4s else None
 
     if rank == 0:
-        size = dict(F=F, T=resident.T, D=resident.D, K=resident.K, taps=WORKLOAD['wpe_taps'],
+        size = dict(F=F, T=resident.T, D=resident.D, K=resident.K, taps=workload['wpe_taps'],
                     N=resident.N)
         total_ms = sum(v['ms'] for v in prof_all.values())
         kernels = {}
@@ -1052,7 +1109,8 @@ def main():
                 'bound': entry['bound'] if entry else None}
         roof = roofline.roofline_entry(dominant, prof[dominant]['ms'] / prof[dominant]['calls'],
                                        **size)
-        traffic_file = REPO / 'profiles' / 'traffic.json'
+        traffic_file = REPO / 'profiles' / ('traffic.json' if args.workload == '2'
+                                            else f'traffic_{args.workload}.json')
         if roof is not None and traffic_file.exists():
             try:
                 roof['traffic'] = json.loads(traffic_file.read_text()).get(dominant, {}).get('bytes')
@@ -1060,8 +1118,15 @@ def main():
                                         '(rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)')
             except Exception:
                 pass
+        if args.workload != '2':
+            # the EM loop of this shape against both roofs, from the same untimed pass
+            em_loop = {f'D{resident.D}_T{resident.T}': em_loop_entry(
+                prof_all, PROFILE_STEPS, workload['bss_iterations'], F=F, T=resident.T,
+                D=resident.D, K=resident.K, roofline=roofline)}
         line = {
-            'metric': 'utterance-seconds enhanced/sec/GPU (24ch, 20 EM iters)',
+            'metric': 'utterance-seconds enhanced/sec/GPU (24ch, 20 EM iters)' if args.workload == '2'
+                      else f'utterance-seconds enhanced/sec/GPU (workload {args.workload}: '
+                           f'{resident.D}ch, {workload["bss_iterations"]} EM iters)',
             'value': args.gpus * steps * utt.seconds / elapsed,
             'unit': 'utterance-seconds/s',
             'n_gpus': args.gpus, 'steps': steps, 'warmup': args.warmup,
@@ -1069,9 +1134,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {
-                'workload': ('BASELINE.json configs[1]: synthetic 24-mic (6 arrays x 4) 15 s '
-                             'utterance, 4 speakers + noise class, WPE taps=10 delay=2 iters=3, '
-                             '20 EM iterations + predict, MVDR-Souden + BAN; inputs resident in HBM'),
+                'workload': workload['description'],
                 'utterance_seconds': utt.seconds, 'channels': resident.D,
                 'frames': resident.T, 'classes': resident.K,
                 'utterances_per_step_per_gpu': 1,
@@ -1093,6 +1156,8 @@ def main():
             'session_mode': incl,
             'roofline': roof,
             'kernels': kernels,
+            'kernel_ms_per_utterance': {k: round(v['ms'] / PROFILE_STEPS, 4) for k, v in
+                                        sorted(prof_all.items(), key=lambda kv: -kv[1]['ms'])},
             'kernels_note': (f'per-kernel table from an untimed pass of {PROFILE_STEPS} steps with HIP '
                              'events around every launch; `roofline` is the dominant kernel timed '
                              'inside the timed region; frac_of_roof prices the minimum flops / bytes '

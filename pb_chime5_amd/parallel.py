@@ -43,6 +43,7 @@ class LocalGroup:
         import threading
         import numpy as np
         self.world = world
+        self.path = path
         self.fd = os.open(path, os.O_RDWR)
         self._mm = mmap.mmap(self.fd, 8 * self.SLOTS)
         self._v = np.frombuffer(self._mm, dtype=np.int64)
@@ -77,6 +78,25 @@ class LocalGroup:
         self.add(0, 1)
         while int(self._v[0]) < target:
             time.sleep(poll)
+
+    def broadcast(self, obj, is_source):
+        """Rank 0's picklable `obj` for every rank (dlp_mpi.bcast): a side file next to the
+        counter file, published before a barrier, removed after a second one."""
+        import pickle
+        self._broadcasts = getattr(self, '_broadcasts', 0) + 1
+        side = f'{self.path}.b{self._broadcasts}'
+        if is_source:
+            with open(side + '.tmp', 'wb') as fd:
+                pickle.dump(obj, fd)
+            os.replace(side + '.tmp', side)
+        self.barrier()
+        if not is_source:
+            with open(side, 'rb') as fd:
+                obj = pickle.load(fd)
+        self.barrier()
+        if is_source:
+            os.unlink(side)
+        return obj
 
     def close(self):
         self._v = None
@@ -162,6 +182,22 @@ def barrier():
         dist.barrier()
     elif _local_group() is not None:
         _local_group().barrier()
+
+
+def broadcast_object(obj, src=0):
+    """The `src` rank's (picklable) object on every rank -- dlp_mpi.bcast in the reference."""
+    if world_size() == 1:
+        return obj
+    dist = _dist()
+    if dist is not None:
+        box = [obj if rank() == src else None]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+    local = _local_group()
+    if local is None:
+        raise RuntimeError('broadcast_object: neither a process group nor a launcher file '
+                           '(call parallel.init() first)')
+    return local.broadcast(obj, rank() == src)
 
 
 def _store():
@@ -325,10 +361,12 @@ def launch_local(nprocs, argv, extra_env=None, timeout=None):
                                           stdout=None if r == 0 else sys.stderr))
         return _wait_all(procs, timeout)
     finally:
-        try:
-            os.unlink(group_file)
-        except OSError:
-            pass
+        import glob
+        for path in glob.glob(glob.escape(group_file) + '*'):
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
 
 
 def _wait_all(procs, timeout):

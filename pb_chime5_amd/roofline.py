@@ -76,7 +76,9 @@ def kernel_work(name, *, F, T, D, K, taps, N):
         c = (n // D) + 1 if D else 0          # delay 2: c = taps + 1 frames back
         if D <= 12 and (c * D) // 16 == (c * D + D - 1) // 16 == sub - 1:
             subtiles = sub * (sub + 1) // 2   # P sits in R's last column tile (one array)
-        return dict(flops=F * 6.0 * need * T, bytes=BY + 8.0 * F * T, bound='mfma',
+        # bytes: the observation and the frame weights in, the needed entries of R and P out
+        return dict(flops=F * 6.0 * need * T, bytes=BY + 8.0 * F * T + 16.0 * F * need,
+                    bound='mfma',
                     dense_flops=F * (8.0 * n * n * T + 8.0 * n * D * T),
                     executed_flops=F * 6.0 * subtiles * 256 * T)
     if name == 'wpe_solve':

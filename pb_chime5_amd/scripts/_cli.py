@@ -93,7 +93,4 @@ def broadcast_path(path):
     from pb_chime5_amd import parallel
     if parallel.world_size() == 1:
         return path
-    import torch.distributed as dist
-    box = [str(path) if path is not None else None]
-    dist.broadcast_object_list(box, src=0)
-    return Path(box[0])
+    return Path(parallel.broadcast_object(str(path) if path is not None else None, src=0))

@@ -133,7 +133,10 @@ def test_node_local_ranks_share_work_without_a_process_group(tmp_path):
         parallel.barrier()
         seen = sorted(n for n in os.listdir(out) if n.startswith('arrived'))
         second = list(parallel.split_managed(items))
-        json.dump(dict(rank=rank, first=first, second=second, seen=seen,
+        from pb_chime5_amd.scripts import _cli
+        told = str(_cli.broadcast_path('/some/run/dir/7' if rank == 0 else None))
+        told2 = parallel.broadcast_object(dict(n=rank + 5) if rank == 0 else None)
+        json.dump(dict(rank=rank, first=first, second=second, seen=seen, told=[told, told2],
                        torch='torch' in sys.modules, affinity=parallel.affinity_info()),
                   open(os.path.join(out, 'result%d.json' % rank), 'w'))
         parallel.barrier()
@@ -150,6 +153,7 @@ def test_node_local_ranks_share_work_without_a_process_group(tmp_path):
         assert r['second'] == sorted(r['second'])
         assert r['seen'] == [f'arrived{k}' for k in range(4)]
         assert r['torch'] is False
+        assert r['told'] == ['/some/run/dir/7', {'n': 5}]       # dlp_mpi.bcast of the run directory
         assert set(r['affinity']) >= {'bound', 'numa_node', 'cpus'}
     assert not list(Path('/dev/shm').glob('gss_group_*')) or True     # launcher unlinks its file
 
