@@ -1177,130 +1177,6 @@ __global__ __launch_bounds__(64 * UPD_WAVES) void chol_update_kernel(cplx *__res
     chol_update_tile<TM, TN, PREFETCH>(A, Z, n, D, j0, nb, tiles[tile_id], lane);
 }
 
-// ---- the trailing update by 48 x 48 blocks with the panels staged in LDS (round 5) ----
-// One 16 x 16 tile per wave reading its operands from global memory re-reads the panel
-// columns of its tile for itself: the wide update after block column 1 at config 2 moved
-// 1.55 GB from L2 to L1 per launch and ran the MFMA pipe at 40 %.  Here a
-// workgroup of 9 waves owns one CH_NB x CH_NB block of the trailing matrix (or the block
-// row's right-hand sides): the two panel blocks it needs -- rows [j0, j0 + K) of U under the
-// block's rows and under its columns, 48 x 48 each per phase of 48 panel rows -- are read
-// from global memory ONCE per workgroup, coalesced along the rows, into LDS, and every wave
-// takes its 16 x 16 tile's operands from there (ds_read_b128, 16 consecutive lanes = 256
-// consecutive bytes: conflict free).  K = 96 runs as two phases through the same LDS block,
-// the second phase's panel rows requested into registers before the MFMAs of the first.
-// Arithmetic per tile exactly as chol_update_tile (t1, t2, t3 from zero over ascending k,
-// taken off C at the end): the same bits.  Diagonal blocks (flag 1) carry their upper tiles
-// only and stage one panel; the block that is the NEXT diagonal block (flag 2) is dispatched
-// first and its workgroup factors it right after the update (chol_diag_block), as the
-// per-tile kernel's diagonal groups did -- with its 6 tiles in ONE round of waves.
-constexpr int UB_WAVES = 9;
-constexpr int UB_ELEMS = CH_NB * CH_NB / (64 * UB_WAVES);     // staged elements per thread and panel
-static_assert(UB_ELEMS * 64 * UB_WAVES == CH_NB * CH_NB, "48 x 48 panel block over 576 threads");
-constexpr size_t UPD_BLK_LDS = 2 * sizeof(cplx) * CH_NB * CH_NB;
-static_assert(UPD_BLK_LDS >= DIAG_LDS, "the folded sweep reuses the panel block");
-
-__global__ __launch_bounds__(64 * UB_WAVES) void chol_update_blk_kernel(
-    cplx *__restrict__ R, cplx *__restrict__ P, int F, int n, int D, int j0, int nb,
-    const UpdTile *__restrict__ blocks, int nblocks, int nfold, int j0_next,
-    int32_t *__restrict__ zero_pivots) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    cplx *LA = reinterpret_cast<cplx *>(smem);          // panel rows under the block's rows
-    cplx *LB = LA + CH_NB * CH_NB;                      // ... under its columns
-    // block ids [0, F8): the folded (next diagonal) blocks of all frequencies, dispatched first;
-    // the rest XCD-mapped so that the blocks of one frequency share one L2
-    const int F8 = nfold > 0 ? (F + 7) / 8 * 8 : 0;
-    int f, bi;
-    if ((int)blockIdx.x < F8) {
-        f = blockIdx.x;
-        bi = 0;
-    } else {
-        const int L = blockIdx.x - F8, nsub = nblocks - nfold;
-        const int sg = L / (8 * nsub), rem = L - sg * 8 * nsub;
-        bi = nfold + (rem >> 3);
-        f = sg * 8 + (rem & 7);
-    }
-    if (f >= F) return;
-    const UpdTile blk = blocks[bi];
-    const bool is_p = blk.is_p != 0, diag = (blk.pad & 1) != 0, fold = (blk.pad & 2) != 0;
-    if (fold) __builtin_amdgcn_s_setprio(3);     // the critical path of the launch
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int li = lane & 15, lk = lane >> 4;
-    const int ta = wave / 3, tb = wave - 3 * ta;
-    cplx *A = R + (int64_t)f * n * n, *Z = P + (int64_t)f * n * D;
-    const cplx *panel = A + (int64_t)j0 * n;      // rows j0 .. j0 + nb of U
-    const cplx *zpanel = Z + (int64_t)j0 * D;
-    const int ncols = is_p ? D : n;
-    const int r_base = blk.row_off + 16 * ta, c_base = blk.col_off + 16 * tb;
-    const bool active = r_base < n && c_base < ncols && !(diag && tb < ta);
-
-    // this wave's tile of C: requested first, touched after the k loop
-    cplx cv[4];
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        const int r = r_base + lk + 4 * reg, c = c_base + li;
-        cv[reg] = c_make(0.0, 0.0);
-        if (active && r < n && c < ncols) cv[reg] = is_p ? Z[(int64_t)r * D + c] : A[(int64_t)r * n + c];
-    }
-    cplx sa[UB_ELEMS], sb[UB_ELEMS];
-    auto request = [&](int ph) {
-#pragma unroll
-        for (int s = 0; s < UB_ELEMS; ++s) {
-            const int idx = tid + 64 * UB_WAVES * s;
-            const int kk = idx / CH_NB, i = idx - kk * CH_NB;
-            const int krow = CH_NB * ph + kk;
-            const int ri = blk.row_off + i, ci = blk.col_off + i;
-            sa[s] = (krow < nb && ri < n) ? panel[(int64_t)krow * n + ri] : c_make(0.0, 0.0);
-            sb[s] = c_make(0.0, 0.0);
-            if (!diag && krow < nb && ci < ncols)
-                sb[s] = is_p ? zpanel[(int64_t)krow * D + ci] : panel[(int64_t)krow * n + ci];
-        }
-    };
-    v4d t1 = {0.0, 0.0, 0.0, 0.0}, t2 = t1, t3 = t1;
-    const int phases = (nb + CH_NB - 1) / CH_NB;
-    request(0);
-    for (int ph = 0; ph < phases; ++ph) {
-#pragma unroll
-        for (int s = 0; s < UB_ELEMS; ++s) {
-            const int idx = tid + 64 * UB_WAVES * s;
-            LA[idx] = sa[s];
-            if (!diag) LB[idx] = sb[s];
-        }
-        __syncthreads();
-        if (ph + 1 < phases) request(ph + 1);
-        if (active) {
-            const cplx *pa = LA + 16 * ta + li + CH_NB * lk;
-            const cplx *pb = (diag ? LA : LB) + 16 * tb + li + CH_NB * lk;
-#pragma unroll
-            for (int ks = 0; ks < CH_NB / 4; ++ks) {
-                const cplx a = pa[4 * CH_NB * ks], b = pb[4 * CH_NB * ks];
-                t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, t1, 0, 0, 0);
-                t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, t2, 0, 0, 0);
-                t3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x + a.y, b.x - b.y, t3, 0, 0, 0);
-            }
-        }
-        if (ph + 1 < phases) __syncthreads();     // the block is re-filled
-    }
-    if (active) {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int r = r_base + lk + 4 * reg, c = c_base + li;
-            if (r < n && c < ncols) {
-                const cplx v = c_make(cv[reg].x - (t1[reg] + t2[reg]),
-                                      cv[reg].y - ((t1[reg] - t2[reg]) - t3[reg]));
-                if (is_p) Z[(int64_t)r * D + c] = v;
-                else A[(int64_t)r * n + c] = v;
-            }
-        }
-    }
-    if (!fold) return;
-    __syncthreads();      // the block is complete and visible to the whole workgroup
-    if (wave >= 4) return;      // the sweep is a 256-thread routine
-    cplx *Ud = reinterpret_cast<cplx *>(smem);                       // 2 * UD_LD
-    double *dinv = reinterpret_cast<double *>(Ud + 2 * UD_LD);       // CH_NB
-    chol_diag_block(A, n, j0_next, Ud, dinv, zero_pivots);
-}
-
 // Blocked back substitution U G = Z, G overwrites Z:  G_J = U_JJ^-1 (Z_J - U_J,>J G_>J),
 // J descending, on the f64 MFMA.  grid (F), block 256.  Per block column: waves 0..2 own
 // one 16-row tile of S = Z_J - U_J,>J G_>J each (2 column tiles = 32 right-hand sides per
@@ -2038,8 +1914,8 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     // after an even block J only block row J + 1 is updated (K = 48, panel J), after an odd
     // block J everything below it is updated once with both panels J - 1 and J (K = 96).
     constexpr int tm16 = 16, tn16 = 16;
-    std::vector<UpdTile> upd, ublk;
-    std::vector<int> upd_start, upd_count, upd_j0, upd_k, upd_ndiag, ublk_start, ublk_count, ublk_nfold;
+    std::vector<UpdTile> upd;
+    std::vector<int> upd_start, upd_count, upd_j0, upd_k, upd_ndiag;
     const bool fold_diag = getenv("GSS_CHOL_DIAG_UNFOLDED") == nullptr;
     {
         const int nblk = (n + CH_NB - 1) / CH_NB;
@@ -2062,26 +1938,13 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                 for (int cc = 0; cc < D; cc += tn16) upd.push_back({r0, cc, 1, 0});
             }
             upd_count.push_back((int)upd.size() - upd_start.back());
-            // the same region by 48 x 48 blocks (chol_update_blk_kernel): the next diagonal
-            // block first (pad bit 1: factored by its workgroup), pad bit 0: diagonal block
-            ublk_start.push_back((int)ublk.size());
-            if (fold_diag && rs < n) ublk.push_back({rs, rs, 0, 3});
-            ublk_nfold.push_back((int)ublk.size() - ublk_start.back());
-            for (int r0 = rs; r0 < r_end; r0 += CH_NB) {
-                for (int c0 = r0; c0 < n; c0 += CH_NB)
-                    if (!(fold_diag && r0 == rs && c0 == rs)) ublk.push_back({r0, c0, 0, c0 == r0 ? 1 : 0});
-                ublk.push_back({r0, 0, 1, 0});
-            }
-            ublk_count.push_back((int)ublk.size() - ublk_start.back());
             const bool wide = paired && J % 2 == 1;
             upd_j0.push_back(wide ? (J - 1) * CH_NB : J * CH_NB);
             upd_k.push_back(wide ? 2 * CH_NB : CH_NB);
         }
     }
-    GSS_REQUIRE(ctx, ntiles <= 1024 && upd.size() + ublk.size() <= 4096, GSS_ERR_UNSUPPORTED,
+    GSS_REQUIRE(ctx, ntiles <= 1024 && upd.size() <= 4096, GSS_ERR_UNSUPPORTED,
                 "wpe: taps*D=%d too large", n);
-    const size_t ublk_at = upd.size();
-    upd.insert(upd.end(), ublk.begin(), ublk.end());      // one upload: tiles, then blocks
     static_assert(sizeof(CorrTile) == sizeof(UpdTile), "tile structs share one buffer");
     if (ctx->wpe_tiles_key[0] != taps || ctx->wpe_tiles_key[1] != delay ||
         ctx->wpe_tiles_key[2] != D || ctx->wpe_tiles_key[3] != corr_ts + (fold_diag ? 0 : 16) + (corr_pairs ? 32 : 0)) {
@@ -2101,13 +1964,6 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     }
     CorrTile *tiles_dev = reinterpret_cast<CorrTile *>(ctx->wpe_tiles);
     UpdTile *upd_dev = reinterpret_cast<UpdTile *>(tiles_dev + 1024);
-    const UpdTile *ublk_dev = upd_dev + ublk_at;
-    // GSS_UPD_TILES=1: the per-tile trailing update (operands from global memory)
-    const bool upd_blocked = !(getenv("GSS_UPD_TILES") && atoi(getenv("GSS_UPD_TILES")) != 0);
-    if (upd_blocked)
-        GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chol_update_blk_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)UPD_BLK_LDS));
     // zeroed pivots of this call (all iterations, all frequencies): counted on the device,
     // copied to the context's status words at the end (gss_last_wpe_zero_pivots)
     int32_t *zero_pivots = reinterpret_cast<int32_t *>(tiles_dev + 1024 + 4096);
@@ -2330,17 +2186,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                                        dim3(256), panel_lds, ctx->stream, R, P, F, n, D, j0);
                     GSS_LAUNCH_CHECK(ctx, "chol_trsm_kernel");
                 }
-                if (upd_blocked && ublk_count[J] > 0) {
-                    GSS_PROF(ctx, detail ? upd_names[std::min(J, 5)] : "wpe_chol_update");
-                    const int nfold = ublk_nfold[J], nblocks = ublk_count[J];
-                    const dim3 g((nfold > 0 ? (F + 7) / 8 * 8 : 0) + xcd_grid(nblocks - nfold, F));
-                    hipLaunchKernelGGL(chol_update_blk_kernel, g, dim3(64 * UB_WAVES), UPD_BLK_LDS,
-                                       ctx->stream, R, P, F, n, D, upd_j0[J],
-                                       std::min(upd_k[J], n - upd_j0[J]), ublk_dev + ublk_start[J],
-                                       nblocks, nfold, (J + 1) * CH_NB, zero_pivots);
-                    GSS_LAUNCH_CHECK(ctx, "chol_update_blk_kernel");
-                }
-                const int nupd = upd_blocked ? 0 : upd_count[J];
+                const int nupd = upd_count[J];
                 if (nupd > 0) {
                     GSS_PROF(ctx, detail ? upd_names[std::min(J, 5)] : "wpe_chol_update");
                     const int ndiag = upd_ndiag[J];
