@@ -579,6 +579,10 @@ def parse_args():
     ap.add_argument('--session-utterances', type=int, default=220)
     ap.add_argument('--loaders', type=int, default=3, help='config 4s: loader threads per rank')
     ap.add_argument('--no-config4s', action='store_true')
+    ap.add_argument('--multiarray', default='True', choices=('True', 'False', 'outer_array_mics'),
+                    help="config 4s: get_enhancer(multiarray=...) -- True: all 6 arrays (24 ch); "
+                         "False: the reference's default, the reference array only (4 ch, "
+                         "core.py:572-575); outer_array_mics: the CHiME-6 default (12 ch)")
     ap.add_argument('--items', type=int, default=512,
                     help='config-3 items in the config3_sharded block of a --config 2 run')
     ap.add_argument('--pool', type=int, default=2, help='config-3 base recordings')
@@ -817,7 +821,8 @@ def main():
         barrier()
         t_gen = time.perf_counter() - t_gen
         json_path = root / 'corpus' / 'chime5.json'
-        kw = dict(database_path=str(json_path), multiarray=True, context_samples=240000,
+        multiarray = {'True': True, 'False': False}.get(args.multiarray, args.multiarray)
+        kw = dict(database_path=str(json_path), multiarray=multiarray, context_samples=240000,
                   device_id=device_index)
 
         def obs_samples(ex):
@@ -862,8 +867,13 @@ def main():
             'workload': (f'BASELINE.json configs[3] stand-in: synthetic CHiME-5-layout session S02, '
                          f'{args.session_seconds:.0f} s x 24 per-channel PCM16 WAV files '
                          f'({in_bytes / 1e6:.0f} MB) under {base}, {len(examples)} utterances '
-                         '(dev-shaped lengths, 2 x 15 s context, all 6 arrays = 24 ch, K = 5), '
-                         'get_enhancer() defaults: WPE taps=10, 20 EM iterations, MVDR+BAN'),
+                         '(dev-shaped lengths, 2 x 15 s context, '
+                         + {'True': 'multiarray=True: all 6 arrays = 24 ch',
+                            'False': 'multiarray=False, the reference default: the reference array = 4 ch',
+                            'outer_array_mics': 'multiarray=outer_array_mics: 2 microphones of each '
+                                                'of the 6 arrays = 12 ch'}[args.multiarray]
+                         + ', K = 5), get_enhancer() defaults: WPE taps=10, 20 EM iterations, MVDR+BAN'),
+            'multiarray': args.multiarray,
             'driver': 'Enhancer.enhance_session(\'S02\', out) as scripts/run.py calls it',
             'includes': ('JSON database + annotation activity, WAV slice reads into page-locked '
                          'int16 blocks, H2D, enhancement, D2H of the trimmed utterance, peak '
@@ -890,7 +900,7 @@ def main():
         block = config4s_session()
         if rank == 0:
             line = {
-                'metric': 'utterance-seconds enhanced/sec (24ch, 20 EM iters), file-backed session',
+                'metric': 'utterance-seconds enhanced/sec (%sch, 20 EM iters), file-backed session' % {'True': 24, 'False': 4, 'outer_array_mics': 12}[args.multiarray],
                 'value': block['value'], 'unit': 'utterance-seconds/s', 'n_gpus': args.gpus,
                 'steps': block['utterances'], 'warmup': args.inflight + 1,
                 'ms_per_step': 1e3 * block['wall_s'] / block['utterances'],
@@ -1040,20 +1050,20 @@ def main():
                         'value': steps * utt.seconds / elapsed, 'unit': 'utterance-seconds/s',
                         'channels': resident.D, 'frames': resident.T, 'classes': resident.K,
                         'workload': 'configs[1] (the headline)', 'mode': 'one stream, inputs resident in HBM'}
-        # the accuracy switch of the correlation (GSS_CORR_BLOCKED=1: chunk-wise accumulation
+        # the accuracy switch of the correlation (GSS_VARIANT=corr_blocked: chunk-wise accumulation
         # of R and P, read by the library on every call): what it costs on the headline
-        os.environ['GSS_CORR_BLOCKED'] = '1'
+        os.environ['GSS_VARIANT'] = 'corr_blocked'
         try:
             ms_b, res_b = time_resident(ctx, ops, utt, params, 10)
             prof_b = profile_kernels(ctx, res_b, utt, PROFILE_STEPS)
         finally:
-            del os.environ['GSS_CORR_BLOCKED']
+            del os.environ['GSS_VARIANT']
         configs['2-corr-blocked'] = {
             'ms_per_utterance': ms_b, 'utterance_seconds': utt.seconds,
             'value': 1e3 * utt.seconds / ms_b, 'unit': 'utterance-seconds/s',
             'wpe_corr_ms_per_launch': prof_b['wpe_corr']['ms'] / prof_b['wpe_corr']['calls'],
             'wpe_corr_ms_per_launch_default': prof_all['wpe_corr']['ms'] / prof_all['wpe_corr']['calls'],
-            'workload': 'configs[1] with GSS_CORR_BLOCKED=1 (default: off)',
+            'workload': 'configs[1] with GSS_VARIANT=corr_blocked (default: off)',
             'what': 'R and P summed in 64-frame blocks (64 + T / 64 roundings per sum instead of T): the '
                     'distance from an extended-precision WPE falls from 1.8 - 2.0 x the oracle\'s own to '
                     '1.1 - 1.4 x (tests/test_gpu_stages.py, tools/wpe_accuracy.py)',

@@ -693,20 +693,36 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
             const int bi = blk[2 * mb], bj = blk[2 * mb + 1];
             const cplx *ra0 = ys + (2 * bi) * EM_TS, *ra1 = ra0 + EM_TS;
             const cplx *rb0 = ys + (2 * bj) * EM_TS, *rb1 = rb0 + EM_TS;
-            for (int j = fg; j < nfr; j += L.nfg) {
-                const cplx a0 = ra0[j], a1 = ra1[j], b0 = rb0[j], b1 = rb1[j];
+            // The four channel values of a frame are dead once its eight products are formed:
+            // the NEXT frame's values are requested into the same registers right there, in
+            // front of the 40 multiply-adds that only need the products and the weights --
+            // the LDS round trip of a frame runs under the arithmetic of the frame before it
+            // at no cost in registers (the compiler's own pipelining of this loop took 206).
+            // Same frames in the same order per thread: the same bits.
+            int j = fg;
+            cplx a0 = ra0[j], a1 = ra1[j], b0 = rb0[j], b1 = rb1[j];     // (fg < nfg <= EM_TILE)
+            for (; j < nfr; j += L.nfg) {
+                double w[KW];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) w[k] = wk[k * EM_TILE + j];
                 double pr[4], pim[4];
                 pr[0] = a0.x * b0.x + a0.y * b0.y;  pim[0] = a0.y * b0.x - a0.x * b0.y;
                 pr[1] = a0.x * b1.x + a0.y * b1.y;  pim[1] = a0.y * b1.x - a0.x * b1.y;
                 pr[2] = a1.x * b0.x + a1.y * b0.y;  pim[2] = a1.y * b0.x - a1.x * b0.y;
                 pr[3] = a1.x * b1.x + a1.y * b1.y;  pim[3] = a1.y * b1.x - a1.x * b1.y;
+                __builtin_amdgcn_sched_barrier(0);
+                const int jn = min(j + L.nfg, EM_TILE - 1);      // (past the tile: read, not used)
+                a0 = ra0[jn];
+                a1 = ra1[jn];
+                b0 = rb0[jn];
+                b1 = rb1[jn];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < KW; ++k) {
-                    const double w = wk[k * EM_TILE + j];
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        acc[s][k].x = fma(w, pr[s], acc[s][k].x);
-                        acc[s][k].y = fma(w, pim[s], acc[s][k].y);
+                        acc[s][k].x = fma(w[k], pr[s], acc[s][k].x);
+                        acc[s][k].y = fma(w[k], pim[s], acc[s][k].y);
                     }
                 }
             }
@@ -1264,9 +1280,6 @@ constexpr int OC_FRAMES = 256;
 #ifndef GSS_EM4_PRIO
 #define GSS_EM4_PRIO 1
 #endif
-#ifndef GSS_EM4_ABL
-#define GSS_EM4_ABL 0      // timing-only ablations of em_onchip4_kernel (wrong results)
-#endif
 #ifdef GSS_EM4_TRACE
 // tools/em4_trace.py: shader cycles wave 0 of every workgroup spends per phase
 __device__ long long g_em4_phase[1024 * 6];
@@ -1290,29 +1303,7 @@ struct OnchipArgs {
     int F, iterations, iterations_post, force_eigh;
     double eig_floor;
     double *gamma;          // (F, K, T)
-    // The last frequency split over coop_g workgroups (0: not split).  513 = 2 * 256 + 1
-    // frequencies on 256 CUs leave ONE CU with three workgroups, and the launch waits for it
-    // (slowest workgroup 1.3 x the fastest): workgroups F - 1 ... F - 2 + coop_g take every
-    // coop_g-th chunk of frequency F - 1 each, so that eight CUs carry 2 1/8 shares instead of
-    // one carrying 3.  Per iteration they hand their sums to the first of them and receive the
-    // model back through `coop` -- agent-scope atomics only (plain data is not coherent between
-    // the L2s of different XCDs inside a launch): [arrive, ready] counters, coop_g partial
-    // records, one model record.
-    int coop_g;
-    double *coop;
-    cplx *Mq_coop;          // (coop_g, NE, K): each helper's private copy of the model
 };
-
-__device__ __forceinline__ void coop_store(double *p, double v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double coop_load(const double *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void coop_wait(int *flag, int value) {       // one thread
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value)
-        __builtin_amdgcn_s_sleep(16);
-}
 
 // One class per LANE (D = 4): Cholesky factor B = U^H U, X = U^-1, B^-1 = X X^H, ln det and
 // the no-floor certificate of class_update_chol, all in the registers of one lane -- the
@@ -1439,15 +1430,7 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
     constexpr int SCRATCH = (2 * 4 * 4 + D * CH_LD) * sizeof(cplx) + 64;
     static_assert(SCRATCH <= sizeof(double) * (K + NP) * OC_LD, "scratch aliases a wave's rows");
     const int64_t T = a.T;
-    // the last frequency may be shared by coop_g workgroups (OnchipArgs): helper cg takes the
-    // chunks cg, cg + coop_g, ...
-    const bool coop = a.coop_g > 0 && (int)blockIdx.x >= a.F - 1;
-    const int cg = coop ? (int)blockIdx.x - (a.F - 1) : 0;
-    const int f = coop ? a.F - 1 : (int)blockIdx.x;
-    const int sub0 = coop ? cg : 0, sub_step = coop ? a.coop_g : 1;
-    constexpr int PART = K * NP + K;                   // one helper's sums per iteration
-    int *coop_flags = reinterpret_cast<int *>(a.coop);
-    double *coop_part = a.coop + 2, *coop_model = a.coop + 2 + (size_t)(coop ? a.coop_g : 0) * PART;
+    const int f = (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const cplx *yf = a.Yn + (int64_t)f * D * T;
@@ -1485,8 +1468,8 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
 #pragma unroll
             for (int k = 0; k < K; ++k) an[k] = a.act[(int64_t)k * a.act_stride + tc];
         };
-        fetch(sub0);
-        for (int sub = sub0; sub < nsub; sub += sub_step) {
+        fetch(0);
+        for (int sub = 0; sub < nsub; ++sub) {
             // a wave whose 64 frames lie past the end has nothing to do (wave uniform)
             if ((int64_t)sub * OC_FRAMES + 64 * wave >= T) break;
             EM4_T(c_a);
@@ -1499,7 +1482,7 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
             bool on[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) on[k] = valid && an[k] != 0;
-            if (sub + sub_step < nsub) fetch(sub + sub_step);
+            if (sub + 1 < nsub) fetch(sub + 1);
             // products of the frame: slots 0-3 |y_d|^2, then re and im of the 6 upper entries
             double pv[NP];
             {
@@ -1549,16 +1532,11 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
                         if (i + 2 < NP) mrow(i + 2, (i + 2) % 3);
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
-#if GSS_EM4_ABL == 2
-                            q[k] = fma(1.0 + 0.125 * (i + k), pv[i], q[k]);
-#else
                             q[k] = fma(k & 1 ? mb[i % 3][k / 2].y : mb[i % 3][k / 2].x, pv[i], q[k]);
-#endif
                         }
                     }
                 }
                 double ssum = 0.0;
-#ifndef GSS_EM4_LOG_SOFTMAX
                 // pi_k exp(-D ln q_k - ln det_k - max) with D = 4 and no logarithm: relative to
                 // the class with the smallest q it is  (q_min / q_k)^4 * cS[k]  with
                 // cS[k] = pi_k exp(ln det_min - ln det_k)  from the model update -- K
@@ -1578,21 +1556,13 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
                 }
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-#if GSS_EM4_ABL == 1
-                    iq[k] = __builtin_amdgcn_rcp(q[k]);
-#else
                     iq[k] = 1.0 / q[k];
-#endif
                     const double r = qmin * iq[k], r2 = r * r;
                     gam[k] = (r2 * r2) * cS[k];
                     if (masked) gam[k] *= on[k] ? 1.0 : 0.0;
                     ssum += gam[k];
                 }
-#if GSS_EM4_ABL == 1
-                const double is = __builtin_amdgcn_rcp(fmax(ssum, GSS_TINY));
-#else
                 const double is = 1.0 / fmax(ssum, GSS_TINY);
-#endif
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     gam[k] = gam[k] * is;
@@ -1600,28 +1570,6 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
                     // gamma / max(q, 10 tiny)
                     wgt[k] = gam[k] * (q[k] < 10.0 * GSS_TINY ? 1.0 / (10.0 * GSS_TINY) : iq[k]);
                 }
-#else
-                double lp[K], mx = -INFINITY;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    q[k] = fmax(fabs(q[k]), GSS_TINY);
-                    lp[k] = -(double)D * log(q[k]) - logdetS[k];
-                    mx = fmax(mx, lp[k]);
-                }
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    gam[k] = exp(lp[k] - mx) * piS[k];
-                    if (masked) gam[k] *= on[k] ? 1.0 : 0.0;
-                    ssum += gam[k];
-                }
-                ssum = fmax(ssum, GSS_TINY);
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    gam[k] = gam[k] / ssum;
-                    if (aff_eps != 0.0) gam[k] = fmin(fmax(gam[k], aff_eps), 1.0 - aff_eps);
-                    wgt[k] = gam[k] / fmax(q[k], 10.0 * GSS_TINY);
-                }
-#endif
             }
             if (predict) {
 #pragma unroll
@@ -1630,11 +1578,6 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
                 continue;
             }
             EM4_T(c_b);
-#if GSS_EM4_ABL == 3
-#pragma unroll
-            for (int k = 0; k < K; ++k) { acc[k] += wgt[k] * pv[k]; sg[k] += valid ? gam[k] : 0.0; }
-            continue;
-#endif
             wave_sync();                      // this wave's phase M of the previous chunk has read its rows
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -1689,43 +1632,13 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
         }
         __syncthreads();
         static_assert(K * NP <= 2 * OC_LD, "the wave sums fit the first rows");
-        bool update = true;
-        if (!coop) {
-            // B_k = D sum / max(sum gamma, tiny): one entry per thread
-            if (tid < K * NP) {
-                const int k = tid / NP;
-                const double sgk = (sgS[0][k] + sgS[1][k]) + (sgS[2][k] + sgS[3][k]);
-                const double tot = ((&ldsS[0][0][0])[tid] + (&ldsS[1][0][0])[tid]) +
-                                   ((&ldsS[2][0][0])[tid] + (&ldsS[3][0][0])[tid]);
-                bS[k][tid % NP] = ((double)D * tot) / fmax(sgk, GSS_TINY);
-            }
-        } else {
-            // every helper publishes its sums; helper 0 adds them up in helper order
-            if (tid < K * NP)
-                coop_store(coop_part + (size_t)cg * PART + tid,
-                           ((&ldsS[0][0][0])[tid] + (&ldsS[1][0][0])[tid]) +
-                               ((&ldsS[2][0][0])[tid] + (&ldsS[3][0][0])[tid]));
-            else if (tid < PART)
-                coop_store(coop_part + (size_t)cg * PART + tid,
-                           (sgS[0][tid - K * NP] + sgS[1][tid - K * NP]) +
-                               (sgS[2][tid - K * NP] + sgS[3][tid - K * NP]));
-            __syncthreads();
-            if (tid == 0)
-                __hip_atomic_fetch_add(coop_flags, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            update = cg == 0;
-            if (update) {
-                if (tid == 0) coop_wait(coop_flags, a.coop_g * (it + 1));
-                __syncthreads();
-                double tot = 0.0;
-                if (tid < PART)
-                    for (int h = 0; h < a.coop_g; ++h) tot += coop_load(coop_part + (size_t)h * PART + tid);
-                if (tid >= K * NP && tid < PART) {
-                    sgS[0][tid - K * NP] = tot;
-                    sgS[1][tid - K * NP] = sgS[2][tid - K * NP] = sgS[3][tid - K * NP] = 0.0;
-                }
-                __syncthreads();
-                if (tid < K * NP) bS[tid / NP][tid % NP] = ((double)D * tot) / fmax(sgS[0][tid / NP], GSS_TINY);
-            }
+        // B_k = D sum / max(sum gamma, tiny): one entry per thread
+        if (tid < K * NP) {
+            const int k = tid / NP;
+            const double sgk = (sgS[0][k] + sgS[1][k]) + (sgS[2][k] + sgS[3][k]);
+            const double tot = ((&ldsS[0][0][0])[tid] + (&ldsS[1][0][0])[tid]) +
+                               ((&ldsS[2][0][0])[tid] + (&ldsS[3][0][0])[tid]);
+            bS[k][tid % NP] = ((double)D * tot) / fmax(sgk, GSS_TINY);
         }
         if (tid == 0) flagS = 0;
         __syncthreads();
@@ -1733,21 +1646,14 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
         // factorisation breaks down or that fail the no-floor certificate are redone by one
         // wave each with the eigendecomposition of em_eigh
         EM4_T(c_u0);
-        if (update && wave == 0 && lane < K) {
+        if (wave == 0 && lane < K) {
             const int k = lane;
             const double sgk = (sgS[0][k] + sgS[1][k]) + (sgS[2][k] + sgS[3][k]);
             piS[k] = sgk / (double)T;
             double b[NP], m[NP], ld;
 #pragma unroll
             for (int i = 0; i < NP; ++i) b[i] = bS[k][i];
-#if GSS_EM4_ABL == 4
-            bool fast = true;
-            ld = b[0];
-#pragma unroll
-            for (int i = 0; i < NP; ++i) m[i] = b[i];
-#else
             const bool fast = class_update4_lane(b, a.eig_floor, m, ld) && !a.force_eigh;
-#endif
             if (fast) {
 #pragma unroll
                 for (int i = 0; i < NP; ++i) mR[i][k] = m[i];
@@ -1763,7 +1669,7 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
         }
 #endif
         __syncthreads();
-        if (update && flagS != 0) {
+        if (flagS != 0) {
             const int flags = flagS;
             for (int k = wave; k < K; k += 4) {
                 if (!(flags >> k & 1)) continue;
@@ -1798,33 +1704,11 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
             }
             __syncthreads();
         }
-        constexpr int MODEL = NP * 2 * KP;                 // doubles of the model rows
-        if (coop) {
-            // helper 0 hands the model on: the model rows, ln det, pi; the others wait for it
-            double *mS = &mR[0][0];
-            if (update) {
-                if (tid < MODEL) coop_store(coop_model + tid, mS[tid]);
-                else if (tid < MODEL + K) coop_store(coop_model + tid, logdetS[tid - MODEL]);
-                else if (tid < MODEL + 2 * K) coop_store(coop_model + tid, piS[tid - MODEL - K]);
-                __syncthreads();
-                if (tid == 0)
-                    __hip_atomic_store(coop_flags + 1, it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                if (tid == 0) coop_wait(coop_flags + 1, it + 1);
-                __syncthreads();
-                if (tid < MODEL) mS[tid] = coop_load(coop_model + tid);
-                else if (tid < MODEL + K) logdetS[tid - MODEL] = coop_load(coop_model + tid);
-                else if (tid < MODEL + 2 * K) piS[tid - MODEL - K] = coop_load(coop_model + tid);
-                __syncthreads();
-            }
-        }
-#ifndef GSS_EM4_LOG_SOFTMAX
         if (tid < K) {
             double ldmin = INFINITY;
             for (int k = 0; k < K; ++k) ldmin = fmin(ldmin, logdetS[k]);
             cS[tid] = piS[tid] * exp(ldmin - logdetS[tid]);
         }
-#endif
         __syncthreads();
 #ifdef GSS_EM4_TRACE
         {
@@ -1845,11 +1729,8 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
 
 template <int K>
 int launch_onchip4(gss_ctx *ctx, const OnchipArgs &a) {
-    if (a.coop_g > 0)      // arrive / ready counters of the shared frequency
-        GSS_HIP_CHECK(ctx, hipMemsetAsync(a.coop, 0, 16, ctx->stream));
     GSS_PROF(ctx, "em_onchip");
-    hipLaunchKernelGGL(em_onchip4_kernel<K>, dim3(a.F - (a.coop_g > 0 ? 1 : 0) + a.coop_g), dim3(256),
-                       0, ctx->stream, a);
+    hipLaunchKernelGGL(em_onchip4_kernel<K>, dim3(a.F), dim3(256), 0, ctx->stream, a);
     GSS_LAUNCH_CHECK(ctx, "em_onchip4_kernel");
     return GSS_OK;
 }
@@ -1868,7 +1749,7 @@ int em_chunks(int F, int64_t T, int D, int *chunk_frames) {
     // T = 2172, workgroup targets 1536 / 3072: D = 4 0.0295 / 0.0359 ms, D = 12 0.1075 /
     // 0.1228 ms; D = 20 and 24 are flat within 2 %).
     int64_t tiles = (T + EM_TILE - 1) / EM_TILE;
-    static const int forced = getenv("GSS_EM_WGS") ? atoi(getenv("GSS_EM_WGS")) : 0;
+    const int forced = gss_variant("em_wgs", 0);
     const int target = forced > 0 ? forced : (D <= 12 ? 1536 : 3072);
     int64_t want = (target + F - 1) / F;
     if (want < 1) want = 1;
@@ -1918,7 +1799,7 @@ int estep_waves_per_block(int F, int64_t T) {
         const double rounds = wgs / (256.0 * (16 / wpb));
         return rounds / std::ceil(rounds);
     };
-    static const int forced = getenv("GSS_ESTEP_WPB") ? atoi(getenv("GSS_ESTEP_WPB")) : 0;
+    const int forced = gss_variant("estep_wpb", 0);
     if (forced == 1 || forced == 4) return forced;
     return eff(1) > eff(4) ? 1 : 4;
 }
@@ -1978,7 +1859,7 @@ int mstep_resident_slots(gss_ctx *ctx, int D, bool prefetch, int *slots) {
 }
 // (pf_max_d: up to here the tiled M-step prefetches across tiles and keeps the chunked form)
 static int mstep_prefetch_max_d() {
-    static const int v = getenv("GSS_MSTEP_PREFETCH_D") ? atoi(getenv("GSS_MSTEP_PREFETCH_D")) : 12;
+    const int v = gss_variant("mstep_prefetch_d", 12);
     return v;
 }
 
@@ -1986,7 +1867,7 @@ template <int KW>
 int launch_mstep(gss_ctx *ctx, const EmArgs &a, const cplx *Yn, int F, int K, int k0) {
     const size_t lds = wcov_lds_layout(a.D, KW).total;
     GSS_PROF(ctx, "em_mstep");
-    if (Yn && a.D == 4 && KW == K && K >= 2 && K <= 6 && getenv("GSS_MSTEP_TILED") == nullptr) {
+    if (Yn && a.D == 4 && KW == K && K >= 2 && K <= 6 && !gss_variant_set("mstep_tiled")) {
         hipLaunchKernelGGL((mstep_reg_kernel<(KW >= 2 && KW <= 6 ? KW : 2), 4>),
                            dim3(xcd_grid(a.nch, F)), dim3(64), 0, ctx->stream, Yn, a.W, F, a.T,
                            a.nch, a.chunk_frames, a.Bp);
@@ -2067,12 +1948,12 @@ int mstep_resident_slots_k(gss_ctx *ctx, int KW, int D, bool prefetch, int *slot
 // (one array, GSS_MSTEP_CHUNKED=1, few frequencies).
 int mstep_plan(gss_ctx *ctx, int F, int64_t T, int D, int K, MsegPlan *plan) {
     *plan = MsegPlan{};
-    static const int min_d = getenv("GSS_MSTEP_PLAN_MIN_D") ? atoi(getenv("GSS_MSTEP_PLAN_MIN_D")) : 5;
-    if (D < min_d || D <= 4 || getenv("GSS_MSTEP_CHUNKED") != nullptr) return GSS_OK;
+    const int min_d = gss_variant("mstep_plan_min_d", 5);
+    if (D < min_d || D <= 4 || gss_variant_set("mstep_chunked")) return GSS_OK;
     const int ngroups = (K + 7) / 8, per = (K + ngroups - 1) / ngroups;
     int slots = 0;
     GSS_TRY(mstep_resident_slots_k(ctx, per, D, D <= mstep_prefetch_max_d(), &slots));
-    if (const char *e = getenv("GSS_MSTEP_SLOTS")) slots = std::max(1, atoi(e));
+    if (gss_variant("mstep_slots", 0) > 0) slots = gss_variant("mstep_slots", 0);
     const int64_t ntile = (T + EM_TILE - 1) / EM_TILE, N = ntile * F;
     if (N >= (1LL << 30) || ntile < 1) return GSS_OK;
     plan->ntile = (int)ntile;
@@ -2148,7 +2029,7 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     a.gamma = gamma;
     // register-form E-step: normalised observation in (F, D, T) layout, its own
     // (finer) partial sums of gamma
-    const bool reg = estep_reg_supported(D, K) && getenv("GSS_ESTEP_LDS") == nullptr;
+    const bool reg = estep_reg_supported(D, K) && !gss_variant_set("estep_lds");
     const int reg_wpb = estep_waves_per_block(F, T);
     const int reg_nch = reg_wpb * (int)((T + 64 * reg_wpb - 1) / (64 * reg_wpb));
     cplx *Yn = nullptr;
@@ -2186,12 +2067,12 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
                 GSS_ERR_UNSUPPORTED, "cacgmm: D=%d K=%d LDS", D, K);
     const int m = D + (D & 1);
     const size_t eigh_lds = (sizeof(cplx) * 2 * m * m + sizeof(double) * m + 15) / 16 * 16;
-    const int force_eigh = getenv("GSS_FORCE_EIGH") != nullptr;
+    const int force_eigh = gss_variant_set("force_eigh");
     int *need_eigh = arena_alloc_t<int>(ctx, (size_t)F * K);
     // (d1, d2) of the packed triangle, row-major and column-major order (em_chol / em_eigh)
     int *tri_tab = arena_alloc_t<int>(ctx, 2 * (size_t)NE);
     GSS_REQUIRE(ctx, need_eigh && tri_tab, GSS_ERR_NOMEM, "cacgmm workspace");
-    if (!(D == 4 && K >= 2 && K <= 6 && reg && iterations > 0 && getenv("GSS_EM_UNFUSED") == nullptr)) {
+    if (!(D == 4 && K >= 2 && K <= 6 && reg && iterations > 0 && !gss_variant_set("em_unfused"))) {
         hipLaunchKernelGGL(tri_table_kernel, dim3(1), dim3(256), 0, ctx->stream, D, tri_tab);
         GSS_LAUNCH_CHECK(ctx, "tri_table_kernel");
     }
@@ -2219,7 +2100,7 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     };
 
     // one array: the whole EM (all iterations + predict) in one launch (em_onchip4_kernel)
-    if (D == 4 && K >= 2 && K <= 6 && reg && iterations > 0 && getenv("GSS_EM_UNFUSED") == nullptr) {
+    if (D == 4 && K >= 2 && K <= 6 && reg && iterations > 0 && !gss_variant_set("em_unfused")) {
         OnchipArgs o{};
         o.Mq = Mq;
         o.Yn = Yn;
@@ -2232,21 +2113,6 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
         o.force_eigh = force_eigh;
         o.eig_floor = 1e-10;
         o.gamma = gamma;
-        // share the last frequency when the count is one more than the CUs can take in equal
-        // parts (513 on 256 CUs) and there are chunks to share (GSS_EM4_COOP=0: never)
-        const int nsub = (int)((T + OC_FRAMES - 1) / OC_FRAMES);
-        // (off by default: measured +-0 on the 513 frequencies of the bench shapes -- 0.938 vs
-        // 0.940 ms -- and a launch without spin-waits is the safer one when ranks share a GPU;
-        // GSS_EM4_COOP=g: g workgroups share the last frequency)
-        int coop_g = 0;
-        if (const char *e = getenv("GSS_EM4_COOP")) coop_g = std::min(std::max(atoi(e), 0), std::min(nsub, 16));
-        if (coop_g == 1) coop_g = 0;
-        if (coop_g > 0) {
-            o.coop_g = coop_g;
-            o.coop = arena_alloc_t<double>(ctx, 2 + (size_t)coop_g * (K * 16 + K) + 16 * (K + 1) + 2 * K + 8);
-            o.Mq_coop = arena_alloc_t<cplx>(ctx, (size_t)coop_g * NE * K);
-            GSS_REQUIRE(ctx, o.coop && o.Mq_coop, GSS_ERR_NOMEM, "cacgmm workspace");
-        }
         switch (K) {
             case 2: return launch_onchip4<2>(ctx, o);
             case 3: return launch_onchip4<3>(ctx, o);

@@ -2,7 +2,9 @@
 // libgss_hip.so (C ABI declared in include/gss_hip.h).
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "gss_internal.h"
 
@@ -25,12 +27,69 @@ int gss_fail(gss_ctx *ctx, int code, const char *fmt, ...) {
 
 static thread_local std::string g_create_error;
 
+// ------------------------------------------------------------------ GSS_VARIANT
+namespace {
+const char *const kVariantKeys[] = {
+    // wpe.hip
+    "corr_ts", "corr_nw", "corr_blocked", "corr_p_tiles", "chol_diag_unfolded", "apply_ph",
+    "apply_generic", "prof_detail",
+    // cacgmm.hip
+    "em_wgs", "estep_wpb", "estep_lds", "mstep_prefetch_d", "mstep_tiled", "mstep_plan_min_d",
+    "mstep_chunked", "mstep_slots", "force_eigh", "em_unfused"};
+struct VariantTable {
+    std::mutex lock;
+    std::string text;
+    bool parsed = false;
+    std::map<std::string, int> values;
+};
+VariantTable &variant_table() {
+    static VariantTable t;
+    return t;
+}
+}   // namespace
+
+int gss_variant(const char *key, int dflt) {
+    const char *env = getenv("GSS_VARIANT");
+    VariantTable &t = variant_table();
+    std::lock_guard<std::mutex> guard(t.lock);
+    if (!t.parsed || t.text != (env ? env : "")) {
+        t.text = env ? env : "";
+        t.parsed = true;
+        t.values.clear();
+        size_t pos = 0;
+        while (pos < t.text.size()) {
+            size_t end = t.text.find_first_of(", ", pos);
+            if (end == std::string::npos) end = t.text.size();
+            const std::string tok = t.text.substr(pos, end - pos);
+            pos = end + 1;
+            if (tok.empty()) continue;
+            const size_t eq = tok.find('=');
+            const std::string name = tok.substr(0, eq);
+            bool known = false;
+            for (const char *k : kVariantKeys) known = known || name == k;
+            if (!known) {
+                fprintf(stderr, "libgss_hip: GSS_VARIANT names no switch '%s'\n", name.c_str());
+                abort();
+            }
+            t.values[name] = eq == std::string::npos ? 1 : atoi(tok.c_str() + eq + 1);
+        }
+    }
+    const auto it = t.values.find(key);
+    return it == t.values.end() ? dflt : it->second;
+}
+
 extern "C" const char *gss_last_error(gss_ctx *ctx) {
     if (!ctx) return g_create_error.c_str();
     return ctx->error.c_str();
 }
 
-extern "C" const char *gss_version(void) { return "pb_chime5_amd/libgss_hip 0.3 (gfx950, f64)"; }
+extern "C" const char *gss_version(void) {
+#ifdef GSS_EXPERIMENT_BUILD
+    return "pb_chime5_amd/libgss_hip 0.4 EXPERIMENT BUILD (gfx950, f64)";
+#else
+    return "pb_chime5_amd/libgss_hip 0.4 (gfx950, f64)";
+#endif
+}
 
 extern "C" int gss_abi_version(void) { return GSS_ABI_VERSION; }
 

@@ -12,6 +12,21 @@
 
 typedef double2 cplx;  // .x = re, .y = im; bit-compatible with gss_cplx
 
+// Kernel-variant switches for tests and A/B runs: ONE environment variable,
+//     GSS_VARIANT="key=value,key,..."          (a bare key means 1)
+// parsed when its text changes (tests flip it between calls), read through gss_variant().
+// The keys that exist are listed in INTEGRATION.md; an unknown key is an error at the first
+// library call that looks at the string (a typo must not silently run the default).
+int gss_variant(const char *key, int dflt);
+inline bool gss_variant_set(const char *key) { return gss_variant(key, 0) != 0; }
+
+// Experiment builds (tools/build_variant.sh: trace instrumentation, other compile-time
+// constants) must say so: none of these may leak into the library the package ships.
+#if (defined(GSS_CORR_TRACE) || defined(GSS_WCOV_TRACE) || defined(GSS_EM4_TRACE) || \
+     defined(GSS_CHOL_TRACE)) && !defined(GSS_EXPERIMENT_BUILD)
+#error "trace instrumentation needs -DGSS_EXPERIMENT_BUILD=1 (tools/build_variant.sh)"
+#endif
+
 #define GSS_TINY 2.2250738585072014e-308  // np.finfo(np.float64).tiny
 
 // ---------------------------------------------------------------- device math

@@ -16,30 +16,59 @@
 namespace {
 
 constexpr int FFT_THREADS = 256;
+constexpr int STFT_RUN = 8;      // consecutive frames per XCD (stft_kernel's grid mapping)
 
 __device__ __forceinline__ unsigned bitrev(unsigned v, int bits) {
     return __brev(v) >> (32 - bits);
 }
 
-// In-place radix-2 DIT over `nseq` sequences of length n (already bit-reversed)
-// stored back to back in LDS.  inverse: conjugated twiddles, no scaling.
+// In-place radix-2 DIT over `nseq` sequences of length n (already bit-reversed) stored back
+// to back in LDS, two stages per pass: a thread takes the four points that stages s and s + 1
+// connect, runs both butterflies in registers and writes them back -- the same operations in
+// the same order as one stage per pass (the results are the same bits), half the LDS round
+// trips and half the barriers.  An odd stage count starts with one single stage.
+// inverse: conjugated twiddles, no scaling.
 __device__ void fft_lds(cplx *s, int n, int log2n, int nseq, const cplx *tw, bool inverse) {
-    const int half_total = nseq * (n >> 1);
-    for (int stage = 0; stage < log2n; ++stage) {
-        const int half = 1 << stage;
-        const int tw_stride = n >> (stage + 1);
+    int stage = 0;
+    if (log2n & 1) {
+        const int half_total = nseq * (n >> 1);
         for (int b = threadIdx.x; b < half_total; b += blockDim.x) {
-            const int seq = b / (n >> 1);
-            const int i = b - seq * (n >> 1);
-            const int j = i & (half - 1);
-            const int base = ((i >> stage) << (stage + 1)) + j;
-            cplx w = tw[j * tw_stride];
+            cplx *p = s + 2 * b;                    // stage 0: neighbours, twiddle 1
+            cplx w = tw[0];
             if (inverse) w.y = -w.y;
-            cplx *p = s + seq * n + base;
-            const cplx a = p[0];
-            const cplx t = c_mul(p[half], w);
+            const cplx a = p[0], t = c_mul(p[1], w);
             p[0] = c_add(a, t);
-            p[half] = c_sub(a, t);
+            p[1] = c_sub(a, t);
+        }
+        __syncthreads();
+        stage = 1;
+    }
+    const int quarter = n >> 2, quarter_total = nseq * quarter;
+    for (; stage < log2n; stage += 2) {
+        const int half = 1 << stage;
+        const int tw1 = n >> (stage + 1), tw2 = n >> (stage + 2);
+        for (int b = threadIdx.x; b < quarter_total; b += blockDim.x) {
+            const int seq = b / quarter;
+            const int i = b - seq * quarter;
+            const int j = i & (half - 1);
+            cplx *p = s + seq * n + ((i >> stage) << (stage + 2)) + j;
+            cplx w1 = tw[j * tw1], w2a = tw[j * tw2], w2b = tw[(j + half) * tw2];
+            if (inverse) {
+                w1.y = -w1.y;
+                w2a.y = -w2a.y;
+                w2b.y = -w2b.y;
+            }
+            const cplx x0 = p[0], x1 = p[half], x2 = p[2 * half], x3 = p[3 * half];
+            cplx t = c_mul(x1, w1);
+            const cplx y0 = c_add(x0, t), y1 = c_sub(x0, t);
+            t = c_mul(x3, w1);
+            const cplx y2 = c_add(x2, t), y3 = c_sub(x2, t);
+            t = c_mul(y2, w2a);
+            p[0] = c_add(y0, t);
+            p[2 * half] = c_sub(y0, t);
+            t = c_mul(y3, w2b);
+            p[half] = c_add(y1, t);
+            p[3 * half] = c_sub(y1, t);
         }
         __syncthreads();
     }
@@ -58,8 +87,17 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_kernel(
     cplx *s = reinterpret_cast<cplx *>(smem);            // PAIRS * size
     cplx *tw = s + PAIRS * size;                          // size / 2
     unsigned *nz = reinterpret_cast<unsigned *>(tw + size / 2);   // bit c: channel c non-zero
-    const int64_t t = blockIdx.x;
-    const int d0 = blockIdx.y * 2 * PAIRS;
+    // 1-D grid, XCD-mapped (workgroup id L runs on XCD L % 8): every XCD takes runs of
+    // STFT_RUN consecutive frames, all channel groups of a frame next to each other.
+    // Consecutive frames share three quarters of their samples, and the channel groups of a
+    // frame write neighbouring 64-byte pieces of the same lines of Y (F,T,D): with the frames
+    // dealt out round robin every sample was fetched into four L2s.
+    const int ngrp = (D + 2 * PAIRS - 1) / (2 * PAIRS);
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int grp = q % ngrp, tl = q / ngrp;
+    const int64_t t = (int64_t)(tl / STFT_RUN) * (8 * STFT_RUN) + xcd * STFT_RUN + tl % STFT_RUN;
+    if (t >= T) return;
+    const int d0 = grp * 2 * PAIRS;
     const int F = size / 2 + 1;
 
     if (threadIdx.x == 0) *nz = 0u;
@@ -380,7 +418,8 @@ size_t stft_workspace_bytes(int64_t T, int size) {
 template <int PAIRS, typename TIn>
 static void stft_launch(gss_ctx *ctx, const TIn *x, double in_scale, int D, int64_t N, int64_t T,
                         int size, int shift, int pad, cplx *Y) {
-    dim3 grid((unsigned)T, (D + 2 * PAIRS - 1) / (2 * PAIRS));
+    const int64_t runs = (T + 8 * STFT_RUN - 1) / (8 * STFT_RUN);
+    dim3 grid((unsigned)(runs * 8 * STFT_RUN * ((D + 2 * PAIRS - 1) / (2 * PAIRS))));
     const size_t lds = sizeof(cplx) * (PAIRS * size + size / 2) + 16;
     hipLaunchKernelGGL((stft_kernel<PAIRS, TIn>), grid, dim3(FFT_THREADS), lds, ctx->stream, x,
                        in_scale, D, N, T, size, ilog2(size), shift, pad, ctx->win_analysis,

@@ -170,7 +170,7 @@ struct CorrTile {
 // 3M complex product: with t1 = sum ar br, t2 = sum ai bi, t3 = sum (ar+ai)(br-bi)
 //   re(a conj b) = t1 + t2,   im(a conj b) = t3 - t1 + t2
 // -- three real MFMAs per tile and k-step instead of four.
-template <int TS, bool M3, int MASK>
+template <int TS, int MASK>
 __device__ __forceinline__ void corr_chunk(const cplx *S, const double *wS, int D,
                                            const CorrTile &tl, v4d (&t1)[TS][TS],
                                            v4d (&t2)[TS][TS], v4d (&t3)[TS][TS]) {
@@ -218,51 +218,22 @@ __device__ __forceinline__ void corr_chunk(const cplx *S, const double *wS, int 
         double ar[TS], ai[TS], as[TS], br[TS], bi[TS], bd[TS];
 #pragma unroll
         for (int m = 0; m < TS; ++m) {
-#ifdef GSS_EXP_NOVALU       // timing-only ablation (tools/wpe_kprof.py): no operand arithmetic
-            ar[m] = a_cur[m].x;
-            ai[m] = a_cur[m].y;
-            as[m] = a_cur[m].x;
-            br[m] = b_cur[m].x;
-            bi[m] = b_cur[m].y;
-            bd[m] = b_cur[m].y;
-#else
             ar[m] = a_cur[m].x * w_cur;
             ai[m] = a_cur[m].y * w_cur;
             as[m] = ar[m] + ai[m];
             br[m] = b_cur[m].x;
             bi[m] = b_cur[m].y;
             bd[m] = b_cur[m].x - b_cur[m].y;
-#endif
         }
-        if (M3) {
 #pragma unroll
-            for (int a = 0; a < TS; ++a)
+        for (int a = 0; a < TS; ++a)
 #pragma unroll
-                for (int b = 0; b < TS; ++b) {
-                    if (!need(a, b)) continue;
-                    t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], br[b], t1[a][b], 0, 0, 0);
-                    t2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], bi[b], t2[a][b], 0, 0, 0);
-                    t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[a], bd[b], t3[a][b], 0, 0, 0);
-                }
-        } else {
-            // 4M: t1 = re, t3 = im  (t2 unused)
-#pragma unroll
-            for (int a = 0; a < TS; ++a)
-#pragma unroll
-                for (int b = 0; b < TS; ++b) {
-                    if (!need(a, b)) continue;
-                    t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], br[b], t1[a][b], 0, 0, 0);
-                    t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], br[b], t3[a][b], 0, 0, 0);
-                }
-#pragma unroll
-            for (int a = 0; a < TS; ++a)
-#pragma unroll
-                for (int b = 0; b < TS; ++b) {
-                    if (!need(a, b)) continue;
-                    t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], bi[b], t1[a][b], 0, 0, 0);
-                    t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], -bi[b], t3[a][b], 0, 0, 0);
-                }
-        }
+            for (int b = 0; b < TS; ++b) {
+                if (!need(a, b)) continue;
+                t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], br[b], t1[a][b], 0, 0, 0);
+                t2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], bi[b], t2[a][b], 0, 0, 0);
+                t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[a], bd[b], t3[a][b], 0, 0, 0);
+            }
 #pragma unroll
         for (int m = 0; m < TS; ++m) {
             a_cur[m] = a_nxt[m];
@@ -274,7 +245,8 @@ __device__ __forceinline__ void corr_chunk(const cplx *S, const double *wS, int 
 
 // The finished tile of a wave -> R (upper tiles) or P.
 // C/D fragment of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-template <int TS, bool M3, int MASK>
+// (RAW: t1 and t3 already hold the real and imaginary part -- the block-wise accumulation)
+template <int TS, int MASK, bool RAW = false>
 __device__ __forceinline__ void corr_store(const CorrTile &tl, int f, int n, int c, int D,
                                            const v4d (&t1)[TS][TS], const v4d (&t2)[TS][TS],
                                            const v4d (&t3)[TS][TS], cplx *__restrict__ R,
@@ -293,9 +265,9 @@ __device__ __forceinline__ void corr_store(const CorrTile &tl, int f, int n, int
                 if (!need(a, b)) continue;
                 const int r = tl.row_off + 16 * a + lk + 4 * reg;
                 const int cc = tl.col_off + 16 * b + li;
-                const cplx v = M3 ? c_make(t1[a][b][reg] + t2[a][b][reg],
-                                           (t3[a][b][reg] - t1[a][b][reg]) + t2[a][b][reg])
-                                  : c_make(t1[a][b][reg], t3[a][b][reg]);
+                const cplx v = RAW ? c_make(t1[a][b][reg], t3[a][b][reg])
+                                   : c_make(t1[a][b][reg] + t2[a][b][reg],
+                                            (t3[a][b][reg] - t1[a][b][reg]) + t2[a][b][reg]);
                 if (r >= n) continue;
                 if (tl.is_p == 1) {
                     const int d = cc - c * D;
@@ -322,7 +294,7 @@ __device__ __forceinline__ void corr_zero(v4d (&t1)[TS][TS], v4d (&t2)[TS][TS], 
         }
 }
 
-template <int TS, bool M3, int MASK, int NW>
+template <int TS, int MASK, int NW>
 __device__ __forceinline__ void corr_tile_body(
     const cplx *__restrict__ Yf, const double *__restrict__ wf, int64_t T, int D, int n, int c,
     int frames_lds, cplx *S, double *wS, const CorrTile tl, bool active, int f,
@@ -372,12 +344,12 @@ __device__ __forceinline__ void corr_tile_body(
         stage_store(t0);
         __syncthreads();
         if (t0 + CORR_KT < T) stage_load(t0 + CORR_KT);
-        if (active) corr_chunk<TS, M3, MASK>(S, wS, D, tl, t1, t2, t3);
+        if (active) corr_chunk<TS, MASK>(S, wS, D, tl, t1, t2, t3);
     }
-    if (active) corr_store<TS, M3, MASK>(tl, f, n, c, D, t1, t2, t3, R, P);
+    if (active) corr_store<TS, MASK>(tl, f, n, c, D, t1, t2, t3, R, P);
 }
 
-template <int TS, bool M3, int NW>
+template <int TS, int NW>
 __global__ __launch_bounds__(64 * NW) void wpe_corr_kernel(
     const cplx *__restrict__ Y, const double *__restrict__ w, int F, int64_t T, int D, int n,
     int c, int padf, const CorrTile *__restrict__ tiles, int ntiles, cplx *__restrict__ R,
@@ -398,7 +370,7 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_kernel(
     constexpr int FULL = (1 << (TS * TS)) - 1;
     const int mask = __builtin_amdgcn_readfirstlane(active ? tl.mask : 1);
 #define CORR_CASE(M) \
-    case M: corr_tile_body<TS, M3, M, NW>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P); break
+    case M: corr_tile_body<TS, M, NW>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P); break
     if (TS == 2) {
         switch (mask) {
             CORR_CASE(1);
@@ -406,10 +378,10 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_kernel(
             CORR_CASE(5);
             CORR_CASE(11);
             default:
-                corr_tile_body<TS, M3, FULL, NW>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P);
+                corr_tile_body<TS, FULL, NW>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P);
         }
     } else {
-        corr_tile_body<TS, M3, FULL, NW>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P);
+        corr_tile_body<TS, FULL, NW>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P);
     }
 #undef CORR_CASE
 }
@@ -452,95 +424,6 @@ extern "C" int gss_debug_corr_phase(long long *host, int entries, int reset) {
 #define CORR_TRACE(slot)
 #endif
 
-template <bool M3, int MASK, int NW>
-__device__ __forceinline__ void corr_tile_body_dma(
-    const __amdgpu_buffer_rsrc_t rsrc_y, const __amdgpu_buffer_rsrc_t rsrc_w, int64_t T, int D,
-    int n, int c, int pieces, cplx *S0, double *w0, const CorrTile tl, bool active, int f,
-    cplx *__restrict__ R, cplx *__restrict__ P) {
-    constexpr int TS = 2;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int win = pieces * 64;                       // elements per LDS window
-    v4d t1[TS][TS], t2[TS][TS], t3[TS][TS];
-    corr_zero<TS>(t1, t2, t3);
-
-    auto issue = [&](int64_t t0, int b) {
-        cplx *Sb = S0 + b * win;
-        const int64_t g0 = (t0 - c) * (int64_t)D;      // slab index of the window's first element
-        for (int p = wave; p < pieces; p += NW) {
-            const int64_t gp = g0 + p * 64;            // wave-uniform
-            const uint32_t voff = (uint32_t)((gp + lane) * 16);
-            if (gp >= 0) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_void_ptr)(Sb + p * 64), 16,
-                                                         voff, 0, 0, 0);
-            } else if (gp + lane < 0) {
-                Sb[p * 64 + lane] = c_make(0.0, 0.0);
-            } else {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_void_ptr)(Sb + p * 64), 16,
-                                                         voff, 0, 0, 0);
-            }
-        }
-        // the CORR_KT weights of the chunk: 32 lanes x 2 doubles
-        if (wave == NW - 1 && lane < CORR_KT / 2)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void_ptr)(w0 + b * CORR_KT), 16,
-                                                     (uint32_t)((t0 + 2 * lane) * 8), 0, 0, 0);
-    };
-    issue(0, 0);
-    __syncthreads();
-    CORR_TRACE(2);
-    int b = 0;
-    for (int64_t t0 = 0; t0 < T; t0 += CORR_KT, b ^= 1) {
-        if (t0 + CORR_KT < T) issue(t0 + CORR_KT, b ^ 1);
-        if (active) corr_chunk<TS, M3, MASK>(S0 + b * win, w0 + b * CORR_KT, D, tl, t1, t2, t3);
-        __syncthreads();       // window b ^ 1 has landed (vmcnt(0) of every wave) and b is free
-    }
-    CORR_TRACE(3);
-    if (active) corr_store<TS, M3, MASK>(tl, f, n, c, D, t1, t2, t3, R, P);
-    CORR_TRACE(4);
-}
-
-template <bool M3, int NW>
-__global__ __launch_bounds__(64 * NW) void wpe_corr_dma_kernel(
-    const cplx *__restrict__ Y, const double *__restrict__ w, int F, int64_t T, int D, int n,
-    int c, int pieces, const CorrTile *__restrict__ tiles, int ntiles, cplx *__restrict__ R,
-    cplx *__restrict__ P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    cplx *S0 = reinterpret_cast<cplx *>(smem);                       // 2 x pieces * 64
-    double *w0 = reinterpret_cast<double *>(S0 + 2 * pieces * 64);   // 2 x CORR_KT
-
-    int f, grp;
-    if (!xcd_group_map((ntiles + NW - 1) / NW, F, f, grp)) return;
-    CORR_TRACE(1);
-#ifdef GSS_CORR_TRACE
-    if (threadIdx.x == 0 && blockIdx.x < 8192) {
-        g_corr_trace[blockIdx.x * 6 + 0] = grp;
-        g_corr_trace[blockIdx.x * 6 + 5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-    }
-#endif
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile_id = grp * NW + wave;
-    const bool active = tile_id < ntiles;
-    const CorrTile tl = tiles[active ? tile_id : 0];
-    // raw buffer resources (stride 0, range check against the byte count): the frequency's
-    // (T, D) slab and its T weights
-    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<cplx *>(Y + (int64_t)f * T * D), 0, (int)(T * D * 16), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double *>(w + (int64_t)f * T), 0, (int)(T * 8), 0x00020000);
-    const int mask = __builtin_amdgcn_readfirstlane(active ? tl.mask : 1);
-#define CORR_CASE(M) \
-    case M: corr_tile_body_dma<M3, M, NW>(rsrc_y, rsrc_w, T, D, n, c, pieces, S0, w0, tl, active, f, R, P); break
-    switch (mask) {
-        CORR_CASE(1);
-        CORR_CASE(3);
-        CORR_CASE(5);
-        CORR_CASE(11);
-        default:
-            corr_tile_body_dma<M3, 15, NW>(rsrc_y, rsrc_w, T, D, n, c, pieces, S0, w0, tl, active, f, R, P);
-    }
-#undef CORR_CASE
-}
-
 // ---- persistent form: resident workgroups pull (frequency, tile group) items from queues
 // What the workgroup timeline of the one-workgroup-per-item launch shows (tools/corr_trace.py,
 // config 2: 5643 items of ~175 us on 512 resident slots): 10 % of the slot time is the tail of
@@ -556,28 +439,23 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_dma_kernel(
 // items ahead.
 struct CorrQueue {
     int ngroups, gh;      // tile groups per frequency; the first gh are "heavy"
-    int fblock;           // frequencies per queue block (heavy groups of a block, then its light ones)
 };
 
 __device__ __forceinline__ int corr_queue_len(int F, int x) { return (F - x + 7) / 8; }
 
-// item q of queue x -> f * 4096 + group.  The queue of an XCD walks its frequencies in blocks
-// of `fblock`: the heavy tile groups of the block's frequencies first, then their light ones
-// (fewer needed sub-tiles per wave), so that the launch ends on short items AND the light
-// groups of a frequency run soon after its heavy ones, while its slab is still in the XCD's
-// L2 (heavy groups of ALL frequencies first -- fblock >= the queue's length -- fetched the
-// slab 3.2 times per launch: profiles/r04d_traffic.json).
+// item q of queue x -> f * 4096 + group: the heavy tile groups of all of the XCD's frequencies
+// first, then the light ones (fewer needed sub-tiles per wave), so that the launch ends on
+// short items.  (The light groups of a frequency then run long after its heavy ones and its
+// slab is fetched into the L2 3.2 times per launch; queue orders that keep a frequency's
+// groups together -- blocks of 4 - 16 frequencies, or strictly frequency-major -- bring the
+// fetch from 597 MB down to 453 - 589 MB and cost 1.5 - 2.7 % of the launch: measured in
+// round 4, tools/experiments/corr_fmajor_ab.sh, not kept.)
 __device__ __forceinline__ int corr_queue_item(int F, int x, int q, const CorrQueue cq) {
-    const int nf = corr_queue_len(F, x);
-    const int per_block = cq.fblock * cq.ngroups;
-    const int blk = q / per_block;
-    q -= blk * per_block;
-    const int j0 = blk * cq.fblock, nfb = min(cq.fblock, nf - j0);
-    const int heavy = nfb * cq.gh;
-    if (q < heavy) return (x + 8 * (j0 + q / cq.gh)) * 4096 + q % cq.gh;
+    const int heavy = corr_queue_len(F, x) * cq.gh;
+    if (q < heavy) return (x + 8 * (q / cq.gh)) * 4096 + q % cq.gh;
     q -= heavy;
     const int gl = max(cq.ngroups - cq.gh, 1);
-    return (x + 8 * (j0 + q / gl)) * 4096 + cq.gh + q % gl;
+    return (x + 8 * (q / gl)) * 4096 + cq.gh + q % gl;
 }
 
 // next item for this workgroup (thread 0 only): own XCD's queue first, then the others;
@@ -598,7 +476,7 @@ __device__ __forceinline__ int corr_fetch(int *counters, int F, int xcd, int &li
 // instead of T.  The f64 MFMA rounds after every frame; BLAS, which the reference's einsum
 // runs on, sums in blocks: this is the factor 1.8 - 2 between this path and the oracle in
 // their distances from an extended-precision WPE (tests: ..._extended_precision).
-template <bool M3, int MASK, int NW, bool BLOCKED, class Issue>
+template <int MASK, int NW, bool BLOCKED, class Issue>
 __device__ __forceinline__ void corr_item_dma(
     int64_t T, int D, int n, int c, int win, cplx *S0, double *w0, const CorrTile tl, bool active,
     int f, int f_next, int &b, Issue &issue, int *ring_slot, int fetched, cplx *__restrict__ R,
@@ -617,9 +495,6 @@ __device__ __forceinline__ void corr_item_dma(
 #ifdef GSS_CORR_TRACE
         const long long ta = clock64();
 #endif
-#ifdef GSS_EXP_NODMA        // timing-only ablation: no window after the first
-        if (t0 == 0 && f_next == -2)
-#endif
         if (t0 + CORR_KT < T)
             issue(f, t0 + CORR_KT, b ^ 1);
         else if (f_next >= 0)
@@ -627,7 +502,7 @@ __device__ __forceinline__ void corr_item_dma(
 #ifdef GSS_CORR_TRACE
         const long long tb = clock64();
 #endif
-        if (active) corr_chunk<TS, M3, MASK>(S0 + b * win, w0 + b * CORR_KT, D, tl, t1, t2, t3);
+        if (active) corr_chunk<TS, MASK>(S0 + b * win, w0 + b * CORR_KT, D, tl, t1, t2, t3);
         if constexpr (BLOCKED) if (active) {
 #pragma unroll
             for (int a = 0; a < TS; ++a)
@@ -661,18 +536,14 @@ __device__ __forceinline__ void corr_item_dma(
         }
 #endif
     }
-#ifdef GSS_EXP_NOSTORE      // timing-only ablation: the tile is not written
-    if (active && t1[0][0][0] == 1.2345e-300)
-#else
     if (active)
-#endif
     {
-        if constexpr (BLOCKED) corr_store<TS, false, MASK>(tl, f, n, c, D, sre, sre, sim, R, P);    // (re, -, im)
-        else corr_store<TS, M3, MASK>(tl, f, n, c, D, t1, t2, t3, R, P);
+        if constexpr (BLOCKED) corr_store<TS, MASK, true>(tl, f, n, c, D, sre, sre, sim, R, P);    // (re, -, im)
+        else corr_store<TS, MASK>(tl, f, n, c, D, t1, t2, t3, R, P);
     }
 }
 
-template <bool M3, int NW, bool BLOCKED = false>
+template <int NW, bool BLOCKED = false>
 __global__ __launch_bounds__(64 * NW) void wpe_corr_persist_kernel(
     const cplx *__restrict__ Y, const double *__restrict__ w, int F, int64_t T, int D, int n,
     int c, int pieces, const CorrTile *__restrict__ tiles, int ntiles, CorrQueue cq,
@@ -762,7 +633,7 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_persist_kernel(
         int *ring_slot = &ring[(k + 2) % 3];
 #define CORR_CASE(M)                                                                              \
     case M:                                                                                       \
-        corr_item_dma<M3, M, NW, BLOCKED>(T, D, n, c, win, S0, w0, tl, active, f, next < 0 ? -1 : next >> 12, \
+        corr_item_dma<M, NW, BLOCKED>(T, D, n, c, win, S0, w0, tl, active, f, next < 0 ? -1 : next >> 12, \
                                  b, issue, ring_slot, fetched, R, P);                             \
         break
         switch (mask) {
@@ -771,7 +642,7 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_persist_kernel(
             CORR_CASE(5);
             CORR_CASE(11);
             default:
-                corr_item_dma<M3, 15, NW, BLOCKED>(T, D, n, c, win, S0, w0, tl, active, f,
+                corr_item_dma<15, NW, BLOCKED>(T, D, n, c, win, S0, w0, tl, active, f,
                                           next < 0 ? -1 : next >> 12, b, issue, ring_slot, fetched,
                                           R, P);
         }
@@ -808,9 +679,6 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_persist_kernel(
 // A non-positive pivot (exactly singular system, e.g. an all-zero channel) zeroes
 // that row, which reproduces the minimum-norm lstsq fallback of stable_solve
 // (pb_chime5/math/solve.py:95-114) for zero rows / columns.
-#ifndef GSS_EXP_UPD
-#define GSS_EXP_UPD 0
-#endif
 #ifndef GSS_UPD_PREFETCH
 #define GSS_UPD_PREFETCH 1     // k-steps of operands in flight beyond the next one (chol_update)
 #endif
@@ -1005,9 +873,6 @@ __device__ inline void chol_update_tile(cplx *A, cplx *Z, int n, int D, int j0, 
     const int ncols = tl.is_p ? D : n;
 
     auto load_ops = [&](int ks, cplx (&a)[TM], cplx (&b)[TN]) {
-#if GSS_EXP_UPD == 1      // timing-only ablation: no operand loads after the first k-step
-        if (ks > 0) return;
-#endif
         const int kk = 4 * ks + lk;
         const bool kv = kk < nb;
 #pragma unroll
@@ -1079,13 +944,9 @@ __device__ inline void chol_update_tile(cplx *A, cplx *Z, int n, int D, int j0, 
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-#if GSS_EXP_UPD == 2      // timing-only ablation: no MFMAs
-                t1[a][b][0] += a_cur[a].x + b_cur[b].x + as[a] + bd[b];
-#else
                 t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[a].x, b_cur[b].x, t1[a][b], 0, 0, 0);
                 t2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[a].y, b_cur[b].y, t2[a][b], 0, 0, 0);
                 t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[a], bd[b], t3[a][b], 0, 0, 0);
-#endif
             }
         if (PREFETCH) {
 #pragma unroll
@@ -1380,7 +1241,7 @@ __global__ __launch_bounds__(256, 3) void chol_backsolve_kernel(const cplx *__re
 // advances by 4), and every wrap is three VALU instructions that the MFMA pipe waits for.
 // TAIL: rows r >= n have to be masked -- n is not a multiple of 8 (the loop runs two k-steps per
 // trip, so an odd k-step count executes one k-step past the end).
-template <int TA, int NB, bool M3, int NWV = 4, int WRAPS = 4, bool TAIL = true>
+template <int TA, int NB, int NWV = 4, int WRAPS = 4, bool TAIL = true>
 __global__ __launch_bounds__(64 * NWV) void wpe_apply_kernel(const cplx *__restrict__ Y,
                                                         const cplx *__restrict__ G, int F,
                                                         int64_t T, int D, int n, int c,
@@ -1400,11 +1261,7 @@ __global__ __launch_bounds__(64 * NWV) void wpe_apply_kernel(const cplx *__restr
     // dependent round trips as long as the whole k loop)
     constexpr int PRE = 14, NT = 64 * NWV;
     const int total = frames_lds * D;
-#ifdef GSS_EXP_APPLY_NOSTAGE     // timing-only ablation: the window is not staged (garbage results)
-    for (int base = 0; base < (T < 0 ? total : 0); base += NT * PRE) {
-#else
     for (int base = 0; base < total; base += NT * PRE) {
-#endif
         cplx v[PRE];
 #pragma unroll
         for (int j = 0; j < PRE; ++j) {
@@ -1424,14 +1281,14 @@ __global__ __launch_bounds__(64 * NWV) void wpe_apply_kernel(const cplx *__restr
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
     const int wf0 = wave * WAVE_FRAMES;          // first frame of this wave, tile relative
-    v4d acc_re[TA][NB], acc_im[TA][NB], acc_t2[M3 ? TA : 1][M3 ? NB : 1];
+    v4d acc_re[TA][NB], acc_im[TA][NB], acc_t2[TA][NB];
 #pragma unroll
     for (int a = 0; a < TA; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             acc_re[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
             acc_im[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-            if (M3) acc_t2[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+            acc_t2[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
         }
     // Two k-steps per trip with ping-pong operand registers: G rows (global, L2 resident)
     // and window fragments (LDS) of k-step ks + 1 are requested before the MFMAs of ks are
@@ -1492,37 +1349,20 @@ __global__ __launch_bounds__(64 * NWV) void wpe_apply_kernel(const cplx *__restr
             gi[b] = g[b].y;
         }
         // u * conj(g)
-        if (M3) {
-            // acc_re = t1, acc_t2 = t2, acc_im = t3
-            double us[TA], gd[NB];
+        // acc_re = t1, acc_t2 = t2, acc_im = t3
+        double us[TA], gd[NB];
 #pragma unroll
-            for (int a = 0; a < TA; ++a) us[a] = ur[a] + ui[a];
+        for (int a = 0; a < TA; ++a) us[a] = ur[a] + ui[a];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) gd[b] = gr[b] - gi[b];
+        for (int b = 0; b < NB; ++b) gd[b] = gr[b] - gi[b];
 #pragma unroll
-            for (int a = 0; a < TA; ++a)
+        for (int a = 0; a < TA; ++a)
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[a], gr[b], acc_re[a][b], 0, 0, 0);
-                    acc_t2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui[a], gi[b], acc_t2[a][b], 0, 0, 0);
-                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(us[a], gd[b], acc_im[a][b], 0, 0, 0);
-                }
-        } else {
-#pragma unroll
-            for (int a = 0; a < TA; ++a)
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[a], gr[b], acc_re[a][b], 0, 0, 0);
-                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui[a], gr[b], acc_im[a][b], 0, 0, 0);
-                }
-#pragma unroll
-            for (int a = 0; a < TA; ++a)
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui[a], gi[b], acc_re[a][b], 0, 0, 0);
-                    acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[a], -gi[b], acc_im[a][b], 0, 0, 0);
-                }
-        }
+            for (int b = 0; b < NB; ++b) {
+                acc_re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[a], gr[b], acc_re[a][b], 0, 0, 0);
+                acc_t2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ui[a], gi[b], acc_t2[a][b], 0, 0, 0);
+                acc_im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(us[a], gd[b], acc_im[a][b], 0, 0, 0);
+            }
     };
     cplx g0[NB], g1[NB], u0[TA], u1[TA];
     load_g(0, g0);
@@ -1553,9 +1393,8 @@ __global__ __launch_bounds__(64 * NWV) void wpe_apply_kernel(const cplx *__restr
                 const int64_t t = t0 + fl;
                 if (d < D && t < T) {
                     const cplx y = S[(fl + c) * DP + d];
-                    const double pre = M3 ? acc_re[a][b][reg] + acc_t2[a][b][reg] : acc_re[a][b][reg];
-                    const double pim = M3 ? (acc_im[a][b][reg] - acc_re[a][b][reg]) + acc_t2[a][b][reg]
-                                          : acc_im[a][b][reg];
+                    const double pre = acc_re[a][b][reg] + acc_t2[a][b][reg];
+                    const double pim = (acc_im[a][b][reg] - acc_re[a][b][reg]) + acc_t2[a][b][reg];
                     X[((int64_t)f * T + t) * D + d] = c_make(y.x - pre, y.y - pim);
                 }
             }
@@ -1799,7 +1638,7 @@ static int corr_tiles(int n, int D, int c, int ct, std::vector<CorrTile> &tiles)
     const int last_col = (n - 1) / ct;
     // (16 x 16 tiles only: a diagonal 32 x 32 tile skips its sub-tile below the diagonal)
     const bool p_folded = ct == 16 && (c * D) / ct == last_col && (c * D + D - 1) / ct == last_col &&
-                          getenv("GSS_CORR_P_TILES") == nullptr;
+                          !gss_variant_set("corr_p_tiles");
     for (int r0 = 0; r0 < n; r0 += ct)
         for (int c0 = 0; c0 < n; c0 += ct)
             if (c0 + ct > r0) {
@@ -1900,11 +1739,12 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     // D = 24: 4.16 -> 5.11.
     const int sub16 = (n + 15) / 16;
     int corr_ts = sub16 * (sub16 + 1) / 2 + sub16 * ((D + 15) / 16) <= CORR_FINE_MAX_SUBTILES ? 1 : 2;
-    // GSS_CORR_TS=3: the pair tiling (corr_tiles_pairs) on the 32 x 32 kernels
+    // GSS_VARIANT corr_ts=1|2: force the fine / 32 x 32 tiling; corr_ts=3: the pair tiling
+    // (corr_tiles_pairs) on the 32 x 32 kernels
     bool corr_pairs = false;
-    if (const char *e = getenv("GSS_CORR_TS")) {
-        corr_ts = atoi(e) == 1 ? 1 : 2;
-        corr_pairs = atoi(e) == 3;
+    if (const int e = gss_variant("corr_ts", 0)) {
+        corr_ts = e == 1 ? 1 : 2;
+        corr_pairs = e == 3;
     }
     const int ntiles = corr_pairs ? corr_tiles_pairs(n, D, c, tiles) : corr_tiles(n, D, c, 16 * corr_ts, tiles);
     // trailing-update tiles: 16 x 16, every tile that reaches the upper triangle (larger
@@ -1916,14 +1756,13 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     constexpr int tm16 = 16, tn16 = 16;
     std::vector<UpdTile> upd;
     std::vector<int> upd_start, upd_count, upd_j0, upd_k, upd_ndiag;
-    const bool fold_diag = getenv("GSS_CHOL_DIAG_UNFOLDED") == nullptr;
+    const bool fold_diag = !gss_variant_set("chol_diag_unfolded");
     {
         const int nblk = (n + CH_NB - 1) / CH_NB;
-        static const bool paired = getenv("GSS_UPD_UNPAIRED") == nullptr;
         for (int J = 0; J < nblk; ++J) {
             upd_start.push_back((int)upd.size());
             const int rs = (J + 1) * CH_NB;
-            const bool narrow = paired && J % 2 == 0;
+            const bool narrow = J % 2 == 0;
             const int r_end = narrow ? std::min(rs + CH_NB, n) : n;
             // the tiles of the next diagonal block first (group 0 factors it in the same
             // launch, see chol_update_kernel), then everything else
@@ -1938,7 +1777,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                 for (int cc = 0; cc < D; cc += tn16) upd.push_back({r0, cc, 1, 0});
             }
             upd_count.push_back((int)upd.size() - upd_start.back());
-            const bool wide = paired && J % 2 == 1;
+            const bool wide = J % 2 == 1;
             upd_j0.push_back(wide ? (J - 1) * CH_NB : J * CH_NB);
             upd_k.push_back(wide ? 2 * CH_NB : CH_NB);
         }
@@ -1972,9 +1811,8 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     int *corr_counters = reinterpret_cast<int *>(tiles_dev + 1024 + 4096 + 1);
 
     const int padf = corr_padf(D, 16 * corr_ts);
-    // 3 real MFMAs per complex product (t1 = ar br, t2 = ai bi, t3 = (ar + ai)(br - bi));
-    // GSS_CORR_4M=1 selects the 4-product form
-    const bool corr_3m = getenv("GSS_CORR_4M") == nullptr;
+    // (everywhere: 3 real MFMAs per complex product -- t1 = ar br, t2 = ai bi,
+    // t3 = (ar + ai)(br - bi); the 4-product forms were removed in round 5)
     // Waves per workgroup.  A workgroup lives for the whole frame loop, so the launch runs in
     // ceil(workgroups / resident slots) rounds: with F = 513 = 2 * 256 + 1 frequencies the
     // 4-wave form can leave a last round almost empty (D = 12, taps 10: 2052 workgroups on
@@ -1989,43 +1827,32 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         return rounds / std::ceil(rounds);
     };
     int corr_nw = corr_ts == 2 && round_eff(2) > round_eff(4) + 0.15 ? 2 : 4;
-    if (const char *e = getenv("GSS_CORR_NW")) corr_nw = atoi(e) == 2 ? 2 : atoi(e) == 1 && corr_ts == 1 ? 1 : 4;
+    const int nw_forced = gss_variant("corr_nw", 0);
+    if (nw_forced) corr_nw = nw_forced == 2 ? 2 : nw_forced == 1 && corr_ts == 1 ? 1 : 4;
     // one array: the window is a few KB, every wave stages its own and the hardware
     // balances single waves (no idle wave in a workgroup, no barrier partner to wait for)
-    if (corr_ts == 1 && (size_t)(CORR_KT + c + padf) * D <= 512 && !getenv("GSS_CORR_NW")) corr_nw = 1;
-    auto corr_fn = corr_ts == 1 && corr_nw == 1
-        ? (corr_3m ? wpe_corr_kernel<1, true, 1> : wpe_corr_kernel<1, false, 1>)
-        : corr_ts == 1
-        ? (corr_nw == 2 ? (corr_3m ? wpe_corr_kernel<1, true, 2> : wpe_corr_kernel<1, false, 2>)
-                        : (corr_3m ? wpe_corr_kernel<1, true, 4> : wpe_corr_kernel<1, false, 4>))
-        : (corr_nw == 2 ? (corr_3m ? wpe_corr_kernel<2, true, 2> : wpe_corr_kernel<2, false, 2>)
-                        : (corr_3m ? wpe_corr_kernel<2, true, 4> : wpe_corr_kernel<2, false, 4>));
+    if (corr_ts == 1 && (size_t)(CORR_KT + c + padf) * D <= 512 && !nw_forced) corr_nw = 1;
+    auto corr_fn = corr_ts == 1 && corr_nw == 1 ? wpe_corr_kernel<1, 1>
+                   : corr_ts == 1 ? (corr_nw == 2 ? wpe_corr_kernel<1, 2> : wpe_corr_kernel<1, 4>)
+                                  : (corr_nw == 2 ? wpe_corr_kernel<2, 2> : wpe_corr_kernel<2, 4>);
     const size_t corr_lds = sizeof(cplx) * (size_t)(CORR_KT + c + padf) * D + sizeof(double) * CORR_KT;
     const size_t panel_lds = sizeof(cplx) * CH_NB * UD_LD + sizeof(double) * CH_NB;
     static_assert(BS_LD <= UD_LD, "S must fit in Ud");
     constexpr int apply_ta = 2;
-    const bool apply_3m = getenv("GSS_APPLY_4M") == nullptr;
-    int apply_nwv = getenv("GSS_APPLY_NWV") ? atoi(getenv("GSS_APPLY_NWV")) : 4;
-    if (apply_nwv != 2 && apply_nwv != 3) apply_nwv = 4;
-    if (!apply_3m) apply_nwv = 4;
+    constexpr int apply_nwv = 4;       // (2 or 3 waves per workgroup: 1.41 / 1.47 vs 1.37 ms, round 4)
     const int apply_frames = 16 * apply_ta * apply_nwv;
-    auto apply_fn = D <= 16 ? (apply_3m ? wpe_apply_kernel<apply_ta, 1, true> : wpe_apply_kernel<apply_ta, 1, false>)
-                            : (apply_3m ? wpe_apply_kernel<apply_ta, 2, true> : wpe_apply_kernel<apply_ta, 2, false>);
-    if (apply_3m && apply_nwv == 2)
-        apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, true, 2> : wpe_apply_kernel<apply_ta, 2, true, 2>;
-    if (apply_3m && apply_nwv == 3)
-        apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, true, 3> : wpe_apply_kernel<apply_ta, 2, true, 3>;
+    auto apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1> : wpe_apply_kernel<apply_ta, 2>;
     // the common case -- four or more channels: one carry per k-step; taps * D a multiple of 8:
-    // no row mask (GSS_APPLY_GENERIC=1: the general form)
+    // no row mask (GSS_VARIANT apply_generic: the general form)
     // (the k loop runs two k-steps per trip: without the row mask the k-step count must be
     // even, i.e. 8 | taps * D -- 36 rows are 9 k-steps and the tenth would add clamped garbage)
-    if (apply_3m && apply_nwv == 4 && D >= 4 && getenv("GSS_APPLY_GENERIC") == nullptr) {
+    if (D >= 4 && !gss_variant_set("apply_generic")) {
         if (n % 8 == 0)
-            apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, true, 4, 1, false>
-                               : wpe_apply_kernel<apply_ta, 2, true, 4, 1, false>;
+            apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, 4, 1, false>
+                               : wpe_apply_kernel<apply_ta, 2, 4, 1, false>;
         else
-            apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, true, 4, 1, true>
-                               : wpe_apply_kernel<apply_ta, 2, true, 4, 1, true>;
+            apply_fn = D <= 16 ? wpe_apply_kernel<apply_ta, 1, 4, 1, true>
+                               : wpe_apply_kernel<apply_ta, 2, 4, 1, true>;
     }
     const size_t apply_lds = sizeof(cplx) * (size_t)(apply_frames + c + 2) * (D | 1);
     // frame phases packed into the N dimension (wpe_apply_packed_kernel): pick the number of
@@ -2033,7 +1860,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     int apply_ph = 1, apply_nt = (D + 15) / 16;
     size_t packed_lds = 0;
     {
-        const int ph_env = getenv("GSS_APPLY_PH") ? atoi(getenv("GSS_APPLY_PH")) : 0;   // tests
+        const int ph_env = gss_variant("apply_ph", 0);   // tests
         bool ph_env_taken = ph_env <= 1;
         double best = (double)((D + 15) / 16) * n;
         for (int ph = 2; ph <= 4; ++ph) {
@@ -2055,11 +1882,11 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                 packed_lds = lds;
             }
         }
-        if (ph_env == 1 || !apply_3m) apply_ph = 1;
+        if (ph_env == 1) apply_ph = 1;
         if (!ph_env_taken) {
             static bool warned = false;      // a forced variant that does not exist for this shape
             if (!warned)
-                fprintf(stderr, "libgss_hip: GSS_APPLY_PH=%d is not available for D=%d taps=%d "
+                fprintf(stderr, "libgss_hip: GSS_VARIANT apply_ph=%d is not available for D=%d taps=%d "
                                 "(column tiles or LDS); using the default\n", ph_env, D, taps);
             warned = true;
         }
@@ -2087,42 +1914,28 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(corr_fn),
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)corr_lds));
-    // 32 x 32 tiles: the window by LDS-DMA into two alternating LDS windows (GSS_CORR_DMA=0:
-    // the register-staged kernel); needs the slab's byte offsets in 31 bits
+    // 32 x 32 tiles: resident workgroups fed from per-XCD item queues, the window by LDS-DMA
+    // into two alternating LDS windows (wpe_corr_persist_kernel); needs the slab's byte
+    // offsets in 31 bits and two windows in half a CU's LDS, else the register-staged kernel
     const int corr_pieces = (int)(((size_t)(CORR_KT + c + padf) * D + 63) / 64);
     const size_t corr_dma_lds = 2 * (sizeof(cplx) * 64 * (size_t)corr_pieces + sizeof(double) * CORR_KT);
-    const bool corr_dma = corr_ts == 2 && corr_3m && (int64_t)T * D * 16 < (1LL << 31) &&
-                          corr_dma_lds <= 80 * 1024 &&
-                          !(getenv("GSS_CORR_DMA") && atoi(getenv("GSS_CORR_DMA")) == 0);
+    const bool corr_persist = corr_ts == 2 && (int64_t)T * D * 16 < (1LL << 31) &&
+                              corr_dma_lds <= 80 * 1024;
     // (two windows of one workgroup take half a CU's LDS at most, so that two workgroups share
     // a CU; resident workgroups do not care how the item count packs into rounds: 4 waves)
-    if (corr_dma && !getenv("GSS_CORR_NW")) corr_nw = 4;
-    auto corr_dma_fn = corr_nw == 2 ? wpe_corr_dma_kernel<true, 2> : wpe_corr_dma_kernel<true, 4>;
-    if (corr_dma && corr_dma_lds > 64 * 1024)
-        GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(corr_dma_fn),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)corr_dma_lds));
-    // ... as resident workgroups fed from per-XCD item queues (GSS_CORR_PERSIST=0: one
-    // workgroup per item)
-    const bool corr_persist = corr_dma && !(getenv("GSS_CORR_PERSIST") && atoi(getenv("GSS_CORR_PERSIST")) == 0);
-    // GSS_CORR_BLOCKED=1 (read on every call): chunk-wise accumulation of R and P
-    const bool corr_blocked = corr_persist && getenv("GSS_CORR_BLOCKED") && atoi(getenv("GSS_CORR_BLOCKED")) != 0;
-    auto corr_persist_fn = corr_blocked ? (corr_nw == 2 ? wpe_corr_persist_kernel<true, 2, true>
-                                                        : wpe_corr_persist_kernel<true, 4, true>)
-                                        : (corr_nw == 2 ? wpe_corr_persist_kernel<true, 2>
-                                                        : wpe_corr_persist_kernel<true, 4>);
-    CorrQueue corr_queue{(ntiles + corr_nw - 1) / corr_nw, 0, 1 << 20};
+    if (corr_persist && !nw_forced) corr_nw = 4;
+    // GSS_VARIANT corr_blocked (read on every call): chunk-wise accumulation of R and P
+    const bool corr_blocked = corr_persist && gss_variant_set("corr_blocked");
+    auto corr_persist_fn = corr_blocked ? (corr_nw == 2 ? wpe_corr_persist_kernel<2, true>
+                                                        : wpe_corr_persist_kernel<4, true>)
+                                        : (corr_nw == 2 ? wpe_corr_persist_kernel<2>
+                                                        : wpe_corr_persist_kernel<4>);
+    CorrQueue corr_queue{(ntiles + corr_nw - 1) / corr_nw, 0};
     int corr_slots = 0;
     if (corr_persist) {
         // heavy groups: the heaviest wave needs 3 or 4 of its tile's 4 sub-tiles
         for (int g = 0; g < corr_queue.ngroups; ++g)
             if (__builtin_popcount(tiles[g * corr_nw].mask) >= 3) corr_queue.gh = g + 1;
-        // GSS_CORR_FMAJOR=1: all groups of a frequency adjacent in the queue (its slab is
-        // fetched into the XCD's L2 once) instead of the heavy groups of all frequencies first
-        if (getenv("GSS_CORR_FMAJOR") && atoi(getenv("GSS_CORR_FMAJOR")) != 0) corr_queue.gh = corr_queue.ngroups;
-        // frequencies per queue block (GSS_CORR_QBLOCK; 0: heavy groups of all frequencies first)
-        const int qb = getenv("GSS_CORR_QBLOCK") ? atoi(getenv("GSS_CORR_QBLOCK")) : 0;
-        corr_queue.fblock = qb > 0 ? qb : 1 << 20;
         if (corr_dma_lds > 64 * 1024)
             GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(corr_persist_fn),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2132,7 +1945,6 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                                &per_cu, reinterpret_cast<const void *>(corr_persist_fn), 64 * corr_nw,
                                corr_dma_lds));
         GSS_HIP_CHECK(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-        if (const char *e = getenv("GSS_CORR_SLOTS_PER_CU")) per_cu = std::min(per_cu, atoi(e));
         corr_slots = std::min(std::max(per_cu, 1) * cus, corr_queue.ngroups * F);
     }
 
@@ -2149,12 +1961,6 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                                ctx->stream, Y, w, F, T, D, n, c, corr_pieces, tiles_dev, ntiles,
                                corr_queue, corr_counters, R, P);
             GSS_LAUNCH_CHECK(ctx, "wpe_corr_persist_kernel");
-        } else if (corr_dma) {
-            GSS_PROF(ctx, "wpe_corr");
-            hipLaunchKernelGGL(corr_dma_fn, dim3(xcd_grid((ntiles + corr_nw - 1) / corr_nw, F)),
-                               dim3(64 * corr_nw), corr_dma_lds, ctx->stream, Y, w, F, T, D, n, c,
-                               corr_pieces, tiles_dev, ntiles, R, P);
-            GSS_LAUNCH_CHECK(ctx, "wpe_corr_dma_kernel");
         } else {
             GSS_PROF(ctx, "wpe_corr");
             hipLaunchKernelGGL(corr_fn, dim3(xcd_grid((ntiles + corr_nw - 1) / corr_nw, F)),
@@ -2165,7 +1971,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
         {
             const int nblk = (n + CH_NB - 1) / CH_NB;
             // GSS_PROF_DETAIL=1: one profile row per block column (tools/wpe_kprof.py)
-            static const bool detail = getenv("GSS_PROF_DETAIL") != nullptr;
+            const bool detail = gss_variant_set("prof_detail");
             static const char *trsm_names[] = {"wpe_chol_trsm_J0", "wpe_chol_trsm_J1", "wpe_chol_trsm_J2",
                                                "wpe_chol_trsm_J3", "wpe_chol_trsm_J4", "wpe_chol_trsm_J5+"};
             static const char *upd_names[] = {"wpe_chol_update_J0", "wpe_chol_update_J1", "wpe_chol_update_J2",

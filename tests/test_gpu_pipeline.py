@@ -762,17 +762,15 @@ def test_kernel_variants_agree(gpu_ctx, D, monkeypatch):
                                                                    dm.T))
     good = cond < 1e8
     assert good.mean() > 0.05, good.mean()
-    for env in ({'GSS_CORR_TS': '2' if D <= 12 else '1'}, {'GSS_CORR_4M': '1', 'GSS_APPLY_4M': '1'},
-                {'GSS_MSTEP_TILED': '1'}, {'GSS_ESTEP_LDS': '1'}, {'GSS_FORCE_EIGH': '1'},
-                {'GSS_CORR_NW': '2'}, {'GSS_APPLY_NWV': '2'}, {'GSS_CHOL_DIAG_UNFOLDED': '1'},
-                {'GSS_APPLY_PH': '1'}, {'GSS_APPLY_PH': '2'},
-                {'GSS_APPLY_PH': '3'}, {'GSS_APPLY_PH': '4'},
-                # round 4: M-step in chunks instead of the static partition, the one-array EM
-                # as separate launches, correlation variants (one workgroup per item, other
-                # queue orders, block-wise accumulation)
-                {'GSS_MSTEP_CHUNKED': '1'}, {'GSS_MSTEP_SLOTS': '100'}, {'GSS_EM_UNFUSED': '1'},
-                {'GSS_CORR_PERSIST': '0'}, {'GSS_CORR_QBLOCK': '4'}, {'GSS_CORR_FMAJOR': '1'},
-                {'GSS_CORR_BLOCKED': '1'}, {'GSS_CORR_TS': '3'}, {'GSS_APPLY_GENERIC': '1'}):
+    for variant in ('corr_ts=2' if D <= 12 else 'corr_ts=1', 'mstep_tiled', 'estep_lds',
+                    'force_eigh', 'corr_nw=2', 'chol_diag_unfolded',
+                    'apply_ph=1', 'apply_ph=2', 'apply_ph=3', 'apply_ph=4',
+                    # M-step in chunks instead of the static partition, the one-array EM as
+                    # separate launches, block-wise accumulation and pair tiles in the
+                    # correlation, the general form of the filter application; two at once
+                    'mstep_chunked', 'mstep_slots=100', 'em_unfused', 'corr_blocked', 'corr_ts=3',
+                    'apply_generic', 'corr_p_tiles', 'estep_lds,force_eigh,corr_ts=3'):
+        env = {'GSS_VARIANT': variant}
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         other, odet = run()

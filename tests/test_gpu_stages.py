@@ -174,10 +174,10 @@ def test_wpe_config2_bins_within_oracle_noise_of_extended_precision(gpu_ctx, gol
     MFMA rounds after every one of the 941 frames, BLAS sums in blocks -- a NumPy
     restatement that accumulates frame by frame lands on the same 1.8e-11 in bin 169)."""
     from pb_chime5_amd import ops
-    # GSS_CORR_BLOCKED=1: R and P summed in 64-frame blocks like BLAS does -- within 1.6 x of the
+    # GSS_VARIANT=corr_blocked: R and P summed in 64-frame blocks like BLAS does -- within 1.6 x of the
     # oracle's own distance (measured 1.1 - 1.4 x); the default is the frame-by-frame sum
     if blocked:
-        monkeypatch.setenv('GSS_CORR_BLOCKED', '1')
+        monkeypatch.setenv('GSS_VARIANT', 'corr_blocked')
     bound = 1.6 if blocked else 3.0
     g = golden('wpe_truth_config2.npz')
     Y, taps, delay = g['Y'], int(g['taps']), int(g['delay'])
@@ -371,18 +371,17 @@ def test_cacgmm_matches_oracle(gpu_ctx, D, T, F, K, iters, post):
 def test_cacgmm_one_array_kernel_equals_three_launch_path(gpu_ctx, monkeypatch, K, post):
     """D = 4: the one-launch EM (power-form softmax, sums in another order, model through the
     scalar cache) against the E-step / M-step / model-update launches of every other channel
-    count (GSS_EM_UNFUSED=1) and against its own eigendecomposition path (GSS_FORCE_EIGH=1):
+    count (GSS_VARIANT=em_unfused) and against its own eigendecomposition path (force_eigh):
     the same posteriors to rounding; the oracle is the referee for all of them."""
     from pb_chime5_amd import ops
     rng = np.random.default_rng(40 + K)
     Y, act = _scene(rng, 4, 900, 4, K)
     one = ops.cacgmm_posteriors(Y, act, 8, post, ctx=gpu_ctx)
-    monkeypatch.setenv('GSS_EM_UNFUSED', '1')
+    monkeypatch.setenv('GSS_VARIANT', 'em_unfused')
     three = ops.cacgmm_posteriors(Y, act, 8, post, ctx=gpu_ctx)
-    monkeypatch.delenv('GSS_EM_UNFUSED')
-    monkeypatch.setenv('GSS_FORCE_EIGH', '1')
+    monkeypatch.setenv('GSS_VARIANT', 'force_eigh')
     eigh = ops.cacgmm_posteriors(Y, act, 8, post, ctx=gpu_ctx)
-    monkeypatch.delenv('GSS_FORCE_EIGH')
+    monkeypatch.delenv('GSS_VARIANT')
     want = oracle.gss_block(Y, act, 8, post)
     print(f'K={K} post={post}: one launch vs three {np.max(np.abs(one - three)):.1e}, vs eigh path '
           f'{np.max(np.abs(one - eigh)):.1e}, vs oracle {np.max(np.abs(one - want)):.1e} '
@@ -390,21 +389,6 @@ def test_cacgmm_one_array_kernel_equals_three_launch_path(gpu_ctx, monkeypatch, 
     assert np.max(np.abs(one - three)) < 1e-9
     assert np.max(np.abs(one - eigh)) < 1e-8
     assert np.max(np.abs(one - want)) < 1e-7
-
-
-def test_cacgmm_one_array_shared_last_frequency(gpu_ctx, monkeypatch):
-    """GSS_EM4_COOP=g (off by default): g workgroups of the one-launch EM share the chunks of the
-    last frequency and exchange sums and model through agent-scope atomics.  Same posteriors up
-    to the order of the sums."""
-    from pb_chime5_amd import ops
-    rng = np.random.default_rng(7)
-    Y, act = _scene(rng, 4, 1100, 9, 3)
-    base = ops.cacgmm_posteriors(Y, act, 6, 1, ctx=gpu_ctx)
-    for g in (2, 5):
-        monkeypatch.setenv('GSS_EM4_COOP', str(g))
-        coop = ops.cacgmm_posteriors(Y, act, 6, 1, ctx=gpu_ctx)
-        monkeypatch.delenv('GSS_EM4_COOP')
-        assert np.max(np.abs(coop - base)) < 1e-9, g
 
 
 def test_cacgmm_class_with_fewer_frames_than_channels(gpu_ctx):

@@ -6,7 +6,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 OUT=$R/pb_chime5_amd/lib/variants; mkdir -p $OUT/$NAME
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -fno-fast-math -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form=1"
+FLAGS="-DGSS_EXPERIMENT_BUILD=1 --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -fno-fast-math -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form=1"
 for f in gss_api stft wpe cacgmm mvdr; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c $R/pb_chime5_amd/csrc/$f.hip -o $OUT/$NAME/$f.o &
 done

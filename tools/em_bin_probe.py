@@ -43,8 +43,8 @@ def main():
         o = oracle.gss_block_batched(Of, act, iterations=it, iterations_post=post)[..., 0]
         b = brute_force_guided_em(np.ascontiguousarray(Of[..., 0].T), act, it, post)
         row = [f'iterations {it} post {post}: oracle-brute {np.max(np.abs(o - b)):.1e}']
-        for tag, env in (('GPU', {}), ('GPU eigh', {'GSS_FORCE_EIGH': '1'}),
-                         ('GPU LDS E-step', {'GSS_ESTEP_LDS': '1'})):
+        for tag, env in (('GPU', {}), ('GPU eigh', {'GSS_VARIANT': 'force_eigh'}),
+                         ('GPU LDS E-step', {'GSS_VARIANT': 'estep_lds'})):
             tmp = f'/tmp/em_probe_{tag.replace(" ", "_")}.npy'
             subprocess.run([sys.executable, __file__, '0', '0', str(out / f'em_bin_{want_case}_{f}.npz'),
                             str(it), str(post), tmp], env={**os.environ, **env}, check=True)

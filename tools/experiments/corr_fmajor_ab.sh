@@ -1,4 +1,6 @@
 # A/B of the correlation kernel's queue order: time per launch and L2 -> fabric fetch
+# (round 5: the GSS_CORR_QBLOCK / GSS_CORR_FMAJOR switches this script drove were removed from the
+# library after their A/B runs -- profiles/r04*; the script documents how they were measured)
 # (rocprofv3 --pmc FETCH_SIZE, raw units = 64 B x 1/2) per launch.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
