@@ -693,36 +693,24 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
             const int bi = blk[2 * mb], bj = blk[2 * mb + 1];
             const cplx *ra0 = ys + (2 * bi) * EM_TS, *ra1 = ra0 + EM_TS;
             const cplx *rb0 = ys + (2 * bj) * EM_TS, *rb1 = rb0 + EM_TS;
-            // The four channel values of a frame are dead once its eight products are formed:
-            // the NEXT frame's values are requested into the same registers right there, in
-            // front of the 40 multiply-adds that only need the products and the weights --
-            // the LDS round trip of a frame runs under the arithmetic of the frame before it
-            // at no cost in registers (the compiler's own pipelining of this loop took 206).
-            // Same frames in the same order per thread: the same bits.
-            int j = fg;
-            cplx a0 = ra0[j], a1 = ra1[j], b0 = rb0[j], b1 = rb1[j];     // (fg < nfg <= EM_TILE)
-            for (; j < nfr; j += L.nfg) {
-                double w[KW];
-#pragma unroll
-                for (int k = 0; k < KW; ++k) w[k] = wk[k * EM_TILE + j];
+            // (Requesting the next frame's four channel values into the same registers right
+            // after the eight products, in front of the 40 multiply-adds, keeps the register
+            // count and hides the LDS round trip -- measured in round 5: +-0 at D = 24 / 8,
+            // +7 % at D = 12.  The loop is at its issue bound, not at the LDS latency.)
+            for (int j = fg; j < nfr; j += L.nfg) {
+                const cplx a0 = ra0[j], a1 = ra1[j], b0 = rb0[j], b1 = rb1[j];
                 double pr[4], pim[4];
                 pr[0] = a0.x * b0.x + a0.y * b0.y;  pim[0] = a0.y * b0.x - a0.x * b0.y;
                 pr[1] = a0.x * b1.x + a0.y * b1.y;  pim[1] = a0.y * b1.x - a0.x * b1.y;
                 pr[2] = a1.x * b0.x + a1.y * b0.y;  pim[2] = a1.y * b0.x - a1.x * b0.y;
                 pr[3] = a1.x * b1.x + a1.y * b1.y;  pim[3] = a1.y * b1.x - a1.x * b1.y;
-                __builtin_amdgcn_sched_barrier(0);
-                const int jn = min(j + L.nfg, EM_TILE - 1);      // (past the tile: read, not used)
-                a0 = ra0[jn];
-                a1 = ra1[jn];
-                b0 = rb0[jn];
-                b1 = rb1[jn];
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < KW; ++k) {
+                    const double w = wk[k * EM_TILE + j];
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        acc[s][k].x = fma(w[k], pr[s], acc[s][k].x);
-                        acc[s][k].y = fma(w[k], pim[s], acc[s][k].y);
+                        acc[s][k].x = fma(w, pr[s], acc[s][k].x);
+                        acc[s][k].y = fma(w, pim[s], acc[s][k].y);
                     }
                 }
             }

@@ -762,7 +762,7 @@ def test_kernel_variants_agree(gpu_ctx, D, monkeypatch):
                                                                    dm.T))
     good = cond < 1e8
     assert good.mean() > 0.05, good.mean()
-    for variant in ('corr_ts=2' if D <= 12 else 'corr_ts=1', 'mstep_tiled', 'estep_lds',
+    for variant in ('corr_ts=2' if D <= 12 else 'corr_ts=1', 'corr_ts=1', 'mstep_tiled', 'estep_lds',
                     'force_eigh', 'corr_nw=2', 'chol_diag_unfolded',
                     'apply_ph=1', 'apply_ph=2', 'apply_ph=3', 'apply_ph=4',
                     # M-step in chunks instead of the static partition, the one-array EM as
