@@ -57,7 +57,7 @@ def stft_bin_bytes(F, T, D):
     return 16.0 * F * T * D
 
 
-def kernel_work(name, *, F, T, D, K, taps, N):
+def kernel_work(name, *, F, T, D, K, taps, N, iterations=20):
     """Algorithmic (flops, bytes) of ONE launch of kernel ``name`` at the given
     problem size, and the roof that bounds it."""
     BY = stft_bin_bytes(F, T, D)
@@ -99,6 +99,13 @@ def kernel_work(name, *, F, T, D, K, taps, N):
         dense = (4.0 if name == 'em_mstep' else 8.0) * D * D * K * F * T
         return dict(flops=F * T * NE * (6.0 + 4.0 * K), bytes=BY + 8.0 * F * K * T,
                     bound='valu_f64', dense_flops=dense)
+    if name == 'em_onchip':
+        # one array: all iterations + predict in one launch; per pass the E- and M-step flops of
+        # the Hermitian form (the predict pass has no M-step: counted as a full pass, < 3 % off)
+        NE = D * (D + 1) // 2
+        passes = iterations + 1
+        return dict(flops=passes * 2 * F * T * NE * (6.0 + 4.0 * K), bytes=passes * BY,
+                    bound='valu_f64')
     if name in ('em_eig', 'em_chol'):
         # Cholesky factor + inverse + B^-1 = W^H W of a D x D Hermitian matrix:
         # ~ (8/3 + 8/3 + 8/3) D^3 real flop, plus the chunk reduction
