@@ -15,13 +15,22 @@
     GSS_HIP_CHECK((ctx), hipSetDevice((ctx)->device))
 
 // ------------------------------------------------------------------ errors
+// (gss_host_malloc / gss_host_free are documented as callable from any thread -- the session
+// driver's loader threads grow their staging blocks on the first context while its owner
+// enqueues: the message of a context is written and read under one lock, and
+// gss_last_error() hands out the calling thread's own copy)
+static std::mutex g_error_lock;
+
 int gss_fail(gss_ctx *ctx, int code, const char *fmt, ...) {
     char buf[1024];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (ctx) ctx->error = buf;
+    if (ctx) {
+        std::lock_guard<std::mutex> guard(g_error_lock);
+        ctx->error = buf;
+    }
     return code;
 }
 
@@ -80,7 +89,10 @@ int gss_variant(const char *key, int dflt) {
 
 extern "C" const char *gss_last_error(gss_ctx *ctx) {
     if (!ctx) return g_create_error.c_str();
-    return ctx->error.c_str();
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> guard(g_error_lock);
+    copy = ctx->error;
+    return copy.c_str();
 }
 
 extern "C" const char *gss_version(void) {

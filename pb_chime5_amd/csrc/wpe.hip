@@ -1741,11 +1741,11 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     int corr_ts = sub16 * (sub16 + 1) / 2 + sub16 * ((D + 15) / 16) <= CORR_FINE_MAX_SUBTILES ? 1 : 2;
     // GSS_VARIANT corr_ts=1|2: force the fine / 32 x 32 tiling; corr_ts=3: the pair tiling
     // (corr_tiles_pairs) on the 32 x 32 kernels
-    // 10 - 12 channels (the outer microphones of the CHiME-6 arrays): every wave two sub-tiles
-    // instead of one -- 3 MFMAs per 4 operand products instead of 3 per 8; measured -2.9 % at
-    // D = 10, -0.8 ... -2 % at D = 12, +1 % at D = 8 (round 5, tools/wpe_kprof.py)
-    bool corr_pairs = corr_ts == 1 && D >= 10;
-    if (corr_pairs) corr_ts = 2;
+    // GSS_VARIANT corr_ts=3, the pair tiling on the 32 x 32 kernels (every wave two sub-tiles
+    // instead of one), measures -2.9 % at D = 10 and -0.8 ... -2 % at D = 12 -- and, on the
+    // persistent kernel's queue order, fetches the slab four times (config 5: 2.9 GB per launch
+    // against 0.99 GB for the fine tiling, profiles/r05b_cfg5_traffic.json): not the default
+    bool corr_pairs = false;
     if (const int e = gss_variant("corr_ts", 0)) {
         corr_ts = e == 1 ? 1 : 2;
         corr_pairs = e == 3;

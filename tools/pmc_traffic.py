@@ -17,6 +17,7 @@ LABELS = [
     ('chol_trsm_kernel', 'wpe_chol_trsm'), ('chol_backsolve_kernel', 'wpe_backsolve'),
     ('em_estep_reg_kernel', 'em_estep'), ('em_estep_kernel', 'em_estep_first'),
     ('em_prepare_kernel', 'em_prepare'), ('em_chol_kernel', 'em_chol'), ('em_eigh_kernel', 'em_eigh'),
+    ('em_onchip4_kernel', 'em_onchip'),
     ('mstep_reg_kernel', 'em_mstep'), ('stft_kernel', 'stft'), ('istft_frames_kernel', 'istft_frames'),
     ('istft_ola_kernel', 'istft_ola'), ('mvdr_solve_kernel', 'mvdr_solve'), ('mvdr_apply_kernel', 'mvdr_apply'),
     ('mvdr_ref_kernel', 'mvdr_ref'),
