@@ -669,7 +669,7 @@ def main():
             try:
                 from datetime import timedelta
                 os.environ.setdefault('TORCH_NCCL_BLOCKING_WAIT', '1')
-                g = dist.new_group(backend='nccl', timeout=timedelta(seconds=60))
+                g = dist.new_group(backend='nccl', timeout=timedelta(seconds=180))
             except Exception as e:           # noqa: BLE001 -- anything RCCL throws
                 print(f'bench.py: rank {rank}: no RCCL sub-group ({type(e).__name__}: '
                       f'{str(e)[:200]})', file=sys.stderr)
