@@ -144,9 +144,9 @@ def init(backend=None):
     the work counter use it, so gloo always suffices and is the default; nccl (= RCCL) on
     request (`backend='nccl'` / GSS_DIST_BACKEND=nccl).  On a node with fewer GPUs than ranks
     the ranks share devices (device = LOCAL_RANK % device count)."""
+    bind_to_gpu_numa()       # (a single rank also wants its threads on its GPU's socket)
     if world_size() == 1:
         return None
-    bind_to_gpu_numa()
     if backend is None and not os.environ.get('GSS_DIST_BACKEND') and _local_group() is not None:
         return None                       # node-local ranks of launch_local: no process group
     import torch
