@@ -102,3 +102,24 @@ def test_beamformer_status_word_maps_to_the_reference_exceptions():
         ops._raise_for_ref_channel(-2 - 17)
     with pytest.raises(np.linalg.LinAlgError, match='frequency 0'):
         ops._raise_for_ref_channel(-2)
+
+
+def test_variant_keys_are_documented_and_used():
+    """GSS_VARIANT: the keys the library accepts (csrc/gss_api.hip) are the keys INTEGRATION.md
+    documents and the keys the kernels' host code asks for -- no switch without a reader, no
+    reader without a switch, and no direct getenv left in the kernels' translation units."""
+    import re
+    csrc = REPO / 'pb_chime5_amd' / 'csrc'
+    api = (csrc / 'gss_api.hip').read_text()
+    table = api[api.index('kVariantKeys[] = {'):api.index('};', api.index('kVariantKeys[] = {'))]
+    accepted = set(re.findall(r'"([a-z0-9_]+)"', table))
+    used = set()
+    for name in ('wpe.hip', 'cacgmm.hip', 'stft.hip', 'mvdr.hip'):
+        text = (csrc / name).read_text()
+        used |= set(re.findall(r'gss_variant(?:_set)?\("([a-z0-9_]+)"', text))
+        assert 'getenv' not in text, name
+    assert used == accepted, (sorted(used - accepted), sorted(accepted - used))
+    doc = (REPO / 'INTEGRATION.md').read_text()
+    section = doc[doc.index('## Debug switches'):doc.index('## Replacing `mpiexec')]
+    documented = set(re.findall(r'`([a-z0-9_]+)(?:=[^`]*)?`', section)) & (accepted | used)
+    assert documented == accepted, sorted(accepted - documented)
