@@ -599,6 +599,9 @@ def parse_args():
                          "40 iterations, GEV+BAN); 3i = one dev-shaped item of configs[2] (24 ch, "
                          "34.7 s); 1a = the same item on one array (4 ch, the reference default "
                          "multiarray=False).  The profiles of those shapes are taken with it.")
+    ap.add_argument('--n1-value', type=float, default=None,
+                    help="the same workload's `value` at --gpus 1 (a BENCH record): the line then "
+                         "carries scaling_efficiency_vs_n1 = value / (N x n1) beside value_per_gpu")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-bins', type=int, default=24)
     ap.add_argument('--cpu-workers', type=int, default=None)
@@ -626,6 +629,11 @@ def main():
 
     def emit(line):
         line.setdefault('placement', placement)
+        line.setdefault('physical_gpus', len(set(packages)) or None)
+        line.setdefault('ranks_sharing_a_physical_gpu', gpus_shared_by_ranks)
+        if isinstance(line.get('value'), (int, float)):
+            for k, v in parallel.scaling_rows(line['value'], args.gpus, args.n1_value).items():
+                line.setdefault(k, v)
         os.write(result_fd, (json.dumps(line) + '\n').encode())
 
     import torch
@@ -638,7 +646,9 @@ def main():
     rank, local_rank = parallel.rank(), parallel.local_rank()
     n_dev = torch.cuda.device_count()
     shared_devices = n_dev < int(os.environ.get('LOCAL_WORLD_SIZE', world))
-    device_index = local_rank % n_dev
+    # distinct physical packages first (a CPX-partitioned node exposes 8 logical devices per
+    # GPU: LOCAL_RANK % count would put 8 ranks on the partitions of ONE package)
+    device_index = _capi.default_device()
     torch.cuda.set_device(device_index)
     dist = None
     coll_device = 'cpu'
@@ -692,46 +702,34 @@ def main():
     # it resets its mask) run on the socket of this rank's GPU
     full_mask = os.sched_getaffinity(0)
     affinity = parallel.bind_to_gpu_numa(device_index)
-    placement = [dict(rank=rank, device=device_index, **affinity)]
+    try:
+        bus_id = _capi.device_pci_bus_id(device_index)
+    except Exception:            # noqa: BLE001
+        bus_id = None
+    placement = [dict(rank=rank, device=device_index, pci_bus_id=bus_id, **affinity)]
     if dist is not None:
         gathered = [None] * world
         dist.all_gather_object(gathered, placement[0])
         placement = gathered
+    # two ranks on one physical GPU although the node has a logical device for every rank:
+    # the line says so instead of reporting one GPU's throughput as N GPUs'
+    packages = [_capi.pci_package(p['pci_bus_id']) for p in placement if p.get('pci_bus_id')]
+    gpus_shared_by_ranks = len(packages) - len(set(packages))
+    if gpus_shared_by_ranks and not shared_devices and rank == 0:
+        print(f'bench.py: WARNING: {world} ranks on {len(set(packages))} physical GPUs although '
+              f'{n_dev} logical devices are visible: {placement}', file=sys.stderr)
 
     ctx = Context(device_index)
     _capi._DEFAULT_CTX[device_index] = ctx
 
-    def barrier():
+    def gpu_sync():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if dist is not None:
-            if coll_group is not None:
-                dist.barrier(group=coll_group)
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def max_over_ranks(x):
-        if dist is None:
-            return float(x)
-        t = torch.tensor([x], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=coll_group)
-        return float(t.item())
-
-    def sum_over_ranks(x):
-        if dist is None:
-            return float(x)
-        t = torch.tensor([x], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=coll_group)
-        return float(t.item())
-
-    def gather_over_ranks(values):
-        """[values of rank 0, values of rank 1, ...] (a short list of floats per rank)."""
-        if dist is None:
-            return [list(map(float, values))]
-        t = torch.zeros((world, len(values)), dtype=torch.float64, device=coll_device)
-        t[rank] = torch.tensor(list(values), dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=coll_group)
-        return t.cpu().tolist()
+    # barriers and reductions around every timed region (ranks finish at different times: the
+    # slowest rank's clock is the job's); CPU-tested with gloo in tests/test_parallel_gloo.py
+    timer = parallel.RankTimer(dist, coll_group, coll_device, gpu_sync)
+    barrier, max_over_ranks, sum_over_ranks = timer.barrier, timer.max, timer.sum
+    gather_over_ranks = timer.gather
 
     params = ops.make_params(wpe=True, wpe_taps=WORKLOAD['wpe_taps'],
                              wpe_delay=WORKLOAD['wpe_delay'],
@@ -1045,6 +1043,10 @@ def main():
             configs[name] = {'ms_per_utterance': ms, 'utterance_seconds': u.seconds,
                              'value': 1e3 * u.seconds / ms, 'unit': 'utterance-seconds/s',
                              'channels': res.D, 'frames': res.T, 'classes': res.K,
+                             'f64_peak_frac': roofline.step_peak_frac(
+                                 ms, F=F, T=res.T, D=res.D, K=res.K, taps=p.wpe_taps, N=res.N,
+                                 wpe_iterations=p.wpe_iterations, iterations=p.bss_iterations,
+                                 wpe=bool(p.wpe))['frac'],
                              'workload': note, 'mode': 'one stream, inputs resident in HBM'}
             return res
         timed('1', synthetic.config1(),
@@ -1126,12 +1128,26 @@ def main():
         traffic_file = REPO / 'profiles' / ('traffic.json' if args.workload == '2'
                                             else f'traffic_{args.workload}.json')
         if roof is not None and traffic_file.exists():
+            # a PMC figure from an earlier rocprofv3 pass (tools/collect_profiles.sh), valid only
+            # for the sources it was taken on: stale -> traffic stays null and the line says why
             try:
-                roof['traffic'] = json.loads(traffic_file.read_text()).get(dominant, {}).get('bytes')
-                roof['traffic_note'] = ('HBM-side bytes per launch from profiles/traffic.json '
-                                        '(rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)')
-            except Exception:
-                pass
+                table = json.loads(traffic_file.read_text())
+                meta = table.get('__meta__', {})
+                now = roofline.source_hashes()
+                changed = [f for f in roofline.kernel_sources(dominant)
+                           if meta.get('source_hashes', {}).get(f) != now.get(f)]
+                if changed:
+                    roof['traffic_stale'] = {
+                        'file': f'profiles/{traffic_file.name}', 'sources_changed_since': changed,
+                        'bytes_then': table.get(dominant, {}).get('bytes')}
+                else:
+                    roof['traffic'] = table.get(dominant, {}).get('bytes')
+                    roof['traffic_note'] = (
+                        f'HBM-side bytes per launch from profiles/{traffic_file.name} (rocprofv3 --pmc '
+                        'FETCH_SIZE x2 + WRITE_SIZE, separate passes; taken on sources with the same '
+                        'hashes as the loaded library\'s: ' + ', '.join(roofline.kernel_sources(dominant)) + ')')
+            except Exception as e:      # noqa: BLE001
+                roof['traffic_stale'] = {'error': f'{type(e).__name__}: {e}'}
         if args.workload != '2':
             # the EM loop of this shape against both roofs, from the same untimed pass
             em_loop = {f'D{resident.D}_T{resident.T}': em_loop_entry(
@@ -1177,6 +1193,11 @@ def main():
                              'inside the timed region; frac_of_roof prices the minimum flops / bytes '
                              'of each kernel\'s formulation (pb_chime5_amd/roofline.py)'),
             'device_ms_per_step': total_ms / PROFILE_STEPS,
+            # the whole step against the chip's f64 peak: executed flops / duration / 78.6 TFLOP/s
+            'f64_peak_frac': roofline.step_peak_frac(
+                1e3 * elapsed / steps, F=F, T=resident.T, D=resident.D, K=resident.K,
+                taps=params.wpe_taps, N=resident.N, wpe_iterations=params.wpe_iterations,
+                iterations=params.bss_iterations, wpe=bool(params.wpe)),
             'workspace_bytes': ctx.workspace_bytes(),
             'em_loop': em_loop,
             'configs': configs,

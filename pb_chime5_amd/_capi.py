@@ -366,13 +366,42 @@ def device_pci_bus_id(device_id):
     return buf.value.decode()
 
 
+def pci_package(bus_id):
+    """The part of a PCI address that names the physical package: 'domain:bus:device'.  The
+    logical devices of a partitioned GPU (CPX / NPS modes: up to 8 per package) differ in the
+    function digit at most."""
+    return bus_id.lower().rsplit('.', 1)[0]
+
+
+def pick_device(local_rank, bus_ids):
+    """The logical device of a node-local rank: ranks go to DISTINCT physical packages first
+    (round robin over the packages in device order), and only then to further logical devices
+    of a package.  One logical device per package (the usual 8-GPU node): rank r -> device
+    r % count, as before; a partitioned node with 64 logical devices on 8 packages: ranks 0-7
+    land on 8 different GPUs instead of on the 8 partitions of the first."""
+    packages = {}
+    for index, bus_id in enumerate(bus_ids):
+        packages.setdefault(pci_package(bus_id), []).append(index)
+    groups = list(packages.values())
+    if not groups:
+        return 0
+    mine = groups[local_rank % len(groups)]
+    return mine[(local_rank // len(groups)) % len(mine)]
+
+
 def default_device():
-    """$GSS_DEVICE, else LOCAL_RANK modulo the number of visible GPUs (ranks share
-    devices when a node has fewer GPUs than ranks), else 0."""
+    """$GSS_DEVICE, else by LOCAL_RANK over the visible GPUs, distinct physical packages first
+    (`pick_device`; ranks share devices when a node has fewer GPUs than ranks), else 0."""
     if 'GSS_DEVICE' in os.environ:
         return int(os.environ['GSS_DEVICE'])
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    return local_rank % max(device_count(), 1) if local_rank else 0
+    if not local_rank:
+        return 0
+    count = max(device_count(), 1)
+    try:
+        return pick_device(local_rank, [device_pci_bus_id(i) for i in range(count)])
+    except GssError:
+        return local_rank % count
 
 
 def default_context(device_id=None):

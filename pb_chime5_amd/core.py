@@ -301,6 +301,8 @@ class Enhancer:
                 return int(tree)
             costs = [samples(ex['num_samples']) for ex in it]
         self._enhance_and_write(parallel.split_managed(it, costs=costs), audio_dir)
+        # (split_managed ends without a barrier: this rank's pipeline has drained by now)
+        parallel.barrier()
 
     def _write(self, ex, x_hat, audio_dir):
         if not np.all(np.isfinite(x_hat)):

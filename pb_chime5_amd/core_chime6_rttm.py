@@ -78,6 +78,7 @@ class Enhancer(core.Enhancer):
         indices = parallel.split_managed(range(len(it)), costs=costs)
         # the examples travel without audio; _prepare_example reads it (on the loader thread)
         self._enhance_and_write((dict(it.examples[index]) for index in indices), audio_dir)
+        parallel.barrier()      # (split_managed ends without one; the pipeline has drained)
 
     def _prepare_example(self, ex, dtype=np.float64):
         """core_chime6_rttm.py:228-258.  Examples of ``get_dataset`` carry their audio;

@@ -1932,6 +1932,9 @@ int mstep_resident_slots_k(gss_ctx *ctx, int KW, int D, bool prefetch, int *slot
     return gss_fail(ctx, GSS_ERR_UNSUPPORTED, "cacgmm: KW=%d", KW);
 }
 
+// (segments per frequency the static partition may cut: the partial-sum workspace holds as many)
+static int mstep_maxseg_limit() { return std::min(std::max(gss_variant("mstep_maxseg", 8), 1), 32); }
+
 // The M-step's static partition for (F, T) on this device; S = 0 where the chunked form stays
 // (one array, GSS_MSTEP_CHUNKED=1, few frequencies).
 int mstep_plan(gss_ctx *ctx, int F, int64_t T, int D, int K, MsegPlan *plan) {
@@ -1950,11 +1953,71 @@ int mstep_plan(gss_ctx *ctx, int F, int64_t T, int D, int K, MsegPlan *plan) {
     plan->rem = (int)(N % plan->S);
     for (int f = 0; f < F; ++f) plan->maxseg = std::max(plan->maxseg, mseg_count(*plan, f));
     // (few frequencies on a large chip: a run is a tile or two and a frequency would be cut
-    // into more segments than chunks -- the chunked form stays; the workspace holds 8 records)
-    if (plan->maxseg > 8) *plan = MsegPlan{};
+    // into more segments than chunks -- the chunked form stays)
+    if (plan->maxseg > mstep_maxseg_limit()) *plan = MsegPlan{};
     return GSS_OK;
 }
 
+
+// ------------------------------------------------------------------ frequency blocks
+// Long segments (the RTTM front end cuts 120 s - 400 s contexts, core_chime6_rttm.py:360-364):
+// the unit-normalised observation of ALL frequencies no longer fits the 256 MB Infinity Cache
+// (config 5: 739 MB + 154 MB of weights) and every E-step and M-step launch of every iteration
+// streams it from HBM again.  Frequencies are independent, so the EM CAN run over blocks of
+// frequencies whose observation + weights stay on die -- all iterations and the final predict
+// of a block before the next block starts -- optionally two blocks at a time on two streams
+// (one block's model update under the other's E-step / M-step).
+//   em_l3_mb      budget in MB for what is in flight; 0 = one block            (default 0)
+//   em_l3_fit_mb  up to this many MB of (Yn + W) the EM stays one block anyway  (default 230)
+//   em_streams    blocks in flight (1 | 2)                                      (default 2)
+// MEASURED in round 6 and NOT the default (EXPERIMENTS.md, round 6 item 1): at config 5 the
+// resident blocks are slower per frequency than the launches that stream from HBM (E-step
+// 0.51 vs 0.43 us per frequency, M-step likewise; 6 blocks 48.3 ms, 2 blocks 42.0 ms, one
+// block 41.7 ms per utterance) -- the launches are bound by VALU issue and by their ramp and
+// tail, not by where the bytes come from, and short launches have more ramp and tail.
+// Per-frequency arithmetic is unchanged except for the grouping of the M-step's partial sums
+// (the chunking / static partition depends on the number of frequencies of a launch).
+struct EmBlockPlan {
+    int fb, nblocks, streams;
+};
+EmBlockPlan em_block_plan(int F, int64_t T, int D, int K) {
+    EmBlockPlan p{F, 1, 1};
+    const double per_f = (16.0 * D + 8.0 * K) * (double)T;           // Yn + W per frequency
+    const double mb = 1024.0 * 1024.0;
+    const int fit = gss_variant("em_l3_fit_mb", 230), budget = gss_variant("em_l3_mb", 0);
+    if (budget <= 0 || F <= 8 || per_f * F <= fit * mb) return p;
+    p.streams = gss_variant("em_streams", 2) >= 2 ? 2 : 1;
+    int fb = (int)(budget * mb / p.streams / per_f) / 8 * 8;
+    if (fb < 8) fb = 8;
+    int nb = (F + fb - 1) / fb;
+    if (p.streams == 2 && (nb & 1)) ++nb;                           // pairs
+    fb = ((F + nb - 1) / nb + 7) / 8 * 8;                           // balanced, XCD aligned
+    nb = (F + fb - 1) / fb;
+    if (nb <= 1) return EmBlockPlan{F, 1, 1};
+    p.fb = fb;
+    p.nblocks = nb;
+    return p;
+}
+int em_block_size(const EmBlockPlan &p, int F, int b) { return std::min(p.fb, F - b * p.fb); }
+
+// Per-frequency record counts of the partial-sum arrays (their strides): the largest over the
+// block sizes of the plan.
+struct EmStrides {
+    int nch, bp_nch, reg_nch;
+};
+EmStrides em_strides(const EmBlockPlan &p, int F, int64_t T, int D) {
+    EmStrides s{0, 0, 0};
+    for (int b : {0, p.nblocks - 1}) {
+        const int Fb = em_block_size(p, F, b);
+        int cf;
+        const int nch = em_chunks(Fb, T, D, &cf);
+        const int wpb = estep_waves_per_block(Fb, T);
+        s.nch = std::max(s.nch, nch);
+        s.reg_nch = std::max(s.reg_nch, wpb * (int)((T + 64 * wpb - 1) / (64 * wpb)));
+    }
+    s.bp_nch = std::max(s.nch, mstep_maxseg_limit());
+    return s;
+}
 
 }  // namespace
 
@@ -1973,122 +2036,172 @@ int psd_partials_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const
 
 size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K) {
     const size_t NE = tri_count(D);
-    int cf;
-    const int nch = em_chunks(F, T, D, &cf);
+    const EmBlockPlan bp = em_block_plan(F, T, D, K);
+    const EmStrides st = em_strides(bp, F, T, D);
     size_t b = 0;
     b += align_up(sizeof(cplx) * (size_t)F * NE * K);            // Mq
     b += 2 * align_up(sizeof(double) * (size_t)F * K);           // logdet, pi
     b += align_up(sizeof(double) * (size_t)F * K * T);           // W
-    b += align_up(sizeof(cplx) * (size_t)F * std::max(nch, 8) * K * NE);   // Bp (chunks, or <= 8 segments)
-    b += align_up(sizeof(double) * (size_t)F * nch * K);         // Sg
+    b += align_up(sizeof(cplx) * (size_t)F * st.bp_nch * K * NE);   // Bp (chunks, or segments)
+    b += align_up(sizeof(double) * (size_t)F * st.nch * K);      // Sg
     b += align_up(sizeof(int) * (size_t)F * K);                  // need_eigh
     b += align_up(sizeof(int) * 2 * NE);                         // tri_tab
     b += align_up(sizeof(cplx) * (size_t)F * D * T);             // Yn (register-form E-step)
-    b += align_up(sizeof(double) * (size_t)F * ((T + 63) / 64 + 4) * K);
+    b += align_up(sizeof(double) * (size_t)F * st.reg_nch * K);  // Sg of the register-form E-step
     b += 2 * align_up(16 * (2 + 16 * (K * 17) + 16 * (K + 1) + 2 * K + 8 + 16 * NE * K));   // em_onchip coop
     return b + 4096;
 }
 
+namespace {
+// What the launches of one block of frequencies [f0, f0 + F) work on: every per-frequency array
+// offset to the block's first frequency, strides from the block's own plan.
+struct EmBlock {
+    EmArgs a;
+    int F;
+    cplx *Mq, *Yn;
+    int *need_eigh;
+    double *Sg_lds, *Sg_reg;
+    int nch_lds, reg_nch, bp_nch, sg_nch;
+    hipStream_t stream;
+};
+struct StreamRestore {
+    gss_ctx *ctx;
+    hipStream_t s;
+    ~StreamRestore() { ctx->stream = s; }
+};
+int aux_stream_ready(gss_ctx *ctx) {
+    if (!ctx->aux_stream)
+        GSS_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    if (!ctx->ev_fork) GSS_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    if (!ctx->ev_join) GSS_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    return GSS_OK;
+}
+}   // namespace
+
 int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8_t *act,
                int64_t act_stride, int K, int iterations, int iterations_post, double *gamma) {
     const int NE = tri_count(D);
-    EmArgs a{};
-    a.Y = Y;
-    a.act = act;
-    a.act_stride = act_stride;
-    a.T = T;
-    a.F = F;
-    a.D = D;
-    a.NE = NE;
-    a.nch = em_chunks(F, T, D, &a.chunk_frames);
-    GSS_TRY(mstep_plan(ctx, F, T, D, K, &a.mseg));
-    // partial-sum records per frequency: chunks, or segments of the static partition
-    const int bp_nch = a.mseg.S > 0 ? a.mseg.maxseg : a.nch;
+    const bool reg = estep_reg_supported(D, K) && !gss_variant_set("estep_lds");
+    // one array: the whole EM (all iterations + predict) in one launch (em_onchip4_kernel)
+    const bool onchip = D == 4 && K >= 2 && K <= 6 && reg && iterations > 0 &&
+                        !gss_variant_set("em_unfused");
+    const EmBlockPlan bplan = onchip ? EmBlockPlan{F, 1, 1} : em_block_plan(F, T, D, K);
+    const EmStrides st = em_strides(bplan, F, T, D);
+
     cplx *Mq = arena_alloc_t<cplx>(ctx, (size_t)F * NE * K);
     double *logdet = arena_alloc_t<double>(ctx, (size_t)F * K);
     double *pi = arena_alloc_t<double>(ctx, (size_t)F * K);
-    a.W = arena_alloc_t<double>(ctx, (size_t)F * K * T);
-    a.Bp = arena_alloc_t<cplx>(ctx, (size_t)F * bp_nch * K * NE);
-    a.Sg = arena_alloc_t<double>(ctx, (size_t)F * a.nch * K);
-    GSS_REQUIRE(ctx, Mq && logdet && pi && a.W && a.Bp && a.Sg, GSS_ERR_NOMEM,
-                "cacgmm workspace");
-    a.logdet = logdet;
-    a.pi = pi;
-    a.gamma = gamma;
-    // register-form E-step: normalised observation in (F, D, T) layout, its own
-    // (finer) partial sums of gamma
-    const bool reg = estep_reg_supported(D, K) && !gss_variant_set("estep_lds");
-    const int reg_wpb = estep_waves_per_block(F, T);
-    const int reg_nch = reg_wpb * (int)((T + 64 * reg_wpb - 1) / (64 * reg_wpb));
-    cplx *Yn = nullptr;
-    double *Sg_lds = a.Sg, *Sg_reg = nullptr;
-    const int nch_lds = a.nch;
-    {
-        // the unit-normalised (F, D, T) copy also feeds the M-step of every channel count
-        Yn = arena_alloc_t<cplx>(ctx, (size_t)F * D * T);
-        Sg_reg = arena_alloc_t<double>(ctx, (size_t)F * reg_nch * K);
-        GSS_REQUIRE(ctx, Yn && Sg_reg, GSS_ERR_NOMEM, "cacgmm workspace");
-        GSS_PROF(ctx, "em_prepare");
-        const size_t plds = sizeof(cplx) * (size_t)D * EM_TS + sizeof(double) * 4 * EM_TILE;
-        hipLaunchKernelGGL(em_prepare_kernel,
-                           dim3(xcd_grid((int)((T + EM_TILE - 1) / EM_TILE), F)), dim3(256), plds,
-                           ctx->stream, Y, F, T, D, Yn);
-        GSS_LAUNCH_CHECK(ctx, "em_prepare_kernel");
-    }
-    auto estep = [&](int mode) -> int {
-        if (reg && mode != MODE_FIRST) {
-            a.Sg = Sg_reg;
-            switch (D) {
-                case 24: return launch_estep_reg_k<24>(ctx, K, mode, a, Mq, Yn, F);
-                case 20: return launch_estep_reg_k<20>(ctx, K, mode, a, Mq, Yn, F);
-                case 12: return launch_estep_reg_k<12>(ctx, K, mode, a, Mq, Yn, F);
-                case 10: return launch_estep_reg_k<10>(ctx, K, mode, a, Mq, Yn, F);
-                default: return launch_estep_reg_k<4>(ctx, K, mode, a, Mq, Yn, F);
-            }
-        }
-        a.Sg = Sg_lds;
-        return launch_estep_k(ctx, K, mode, a, Mq, F);
-    };
-
+    double *W = arena_alloc_t<double>(ctx, (size_t)F * K * T);
+    cplx *Bp = arena_alloc_t<cplx>(ctx, (size_t)F * st.bp_nch * K * NE);
+    double *Sg_lds = arena_alloc_t<double>(ctx, (size_t)F * st.nch * K);
+    // the unit-normalised (F, D, T) copy feeds the register-form E-step and the M-step of every
+    // channel count; the register-form E-step has its own (finer) partial sums of gamma
+    cplx *Yn = arena_alloc_t<cplx>(ctx, (size_t)F * D * T);
+    double *Sg_reg = arena_alloc_t<double>(ctx, (size_t)F * st.reg_nch * K);
+    int *need_eigh = arena_alloc_t<int>(ctx, (size_t)F * K);
+    // (d1, d2) of the packed triangle, row-major and column-major order (em_chol / em_eigh)
+    int *tri_tab = arena_alloc_t<int>(ctx, 2 * (size_t)NE);
+    GSS_REQUIRE(ctx, Mq && logdet && pi && W && Bp && Sg_lds && Yn && Sg_reg && need_eigh && tri_tab,
+                GSS_ERR_NOMEM, "cacgmm workspace");
     GSS_REQUIRE(ctx, em_estep_lds(D, K) <= 160 * 1024 &&
                          wcov_lds_layout(D, std::min(K, 8)).total <= 160 * 1024,
                 GSS_ERR_UNSUPPORTED, "cacgmm: D=%d K=%d LDS", D, K);
     const int m = D + (D & 1);
     const size_t eigh_lds = (sizeof(cplx) * 2 * m * m + sizeof(double) * m + 15) / 16 * 16;
     const int force_eigh = gss_variant_set("force_eigh");
-    int *need_eigh = arena_alloc_t<int>(ctx, (size_t)F * K);
-    // (d1, d2) of the packed triangle, row-major and column-major order (em_chol / em_eigh)
-    int *tri_tab = arena_alloc_t<int>(ctx, 2 * (size_t)NE);
-    GSS_REQUIRE(ctx, need_eigh && tri_tab, GSS_ERR_NOMEM, "cacgmm workspace");
-    if (!(D == 4 && K >= 2 && K <= 6 && reg && iterations > 0 && !gss_variant_set("em_unfused"))) {
+    if (!onchip) {
         hipLaunchKernelGGL(tri_table_kernel, dim3(1), dim3(256), 0, ctx->stream, D, tri_tab);
         GSS_LAUNCH_CHECK(ctx, "tri_table_kernel");
     }
 
-    int sg_nch = nch_lds;
-    auto eig = [&]() -> int {
+    auto make_block = [&](int f0, int Fb, hipStream_t stream, EmBlock *blk) -> int {
+        EmBlock &b = *blk;
+        b = EmBlock{};
+        b.F = Fb;
+        b.stream = stream;
+        EmArgs &a = b.a;
+        a.Y = Y + (int64_t)f0 * T * D;
+        a.act = act;
+        a.act_stride = act_stride;
+        a.T = T;
+        a.F = Fb;
+        a.D = D;
+        a.NE = NE;
+        a.nch = em_chunks(Fb, T, D, &a.chunk_frames);
+        GSS_TRY(mstep_plan(ctx, Fb, T, D, K, &a.mseg));
+        // partial-sum records per frequency: chunks, or segments of the static partition
+        b.bp_nch = a.mseg.S > 0 ? a.mseg.maxseg : a.nch;
+        b.nch_lds = a.nch;
+        const int wpb = estep_waves_per_block(Fb, T);
+        b.reg_nch = wpb * (int)((T + 64 * wpb - 1) / (64 * wpb));
+        GSS_REQUIRE(ctx, b.bp_nch <= st.bp_nch && b.nch_lds <= st.nch && b.reg_nch <= st.reg_nch,
+                    GSS_ERR_INVALID, "cacgmm: block strides");
+        b.Mq = Mq + (int64_t)f0 * NE * K;
+        a.logdet = logdet + (int64_t)f0 * K;
+        a.pi = pi + (int64_t)f0 * K;
+        a.W = W + (int64_t)f0 * K * T;
+        a.Bp = Bp + (int64_t)f0 * st.bp_nch * K * NE;
+        b.Sg_lds = Sg_lds + (int64_t)f0 * st.nch * K;
+        b.Sg_reg = Sg_reg + (int64_t)f0 * st.reg_nch * K;
+        a.Sg = b.Sg_lds;
+        a.gamma = gamma + (int64_t)f0 * K * T;
+        b.Yn = Yn + (int64_t)f0 * D * T;
+        b.need_eigh = need_eigh + (int64_t)f0 * K;
+        b.sg_nch = b.nch_lds;
+        return GSS_OK;
+    };
+    auto prepare = [&](EmBlock &b) -> int {
+        GSS_PROF(ctx, "em_prepare");
+        const size_t plds = sizeof(cplx) * (size_t)D * EM_TS + sizeof(double) * 4 * EM_TILE;
+        hipLaunchKernelGGL(em_prepare_kernel,
+                           dim3(xcd_grid((int)((T + EM_TILE - 1) / EM_TILE), b.F)), dim3(256), plds,
+                           ctx->stream, b.a.Y, b.F, T, D, b.Yn);
+        GSS_LAUNCH_CHECK(ctx, "em_prepare_kernel");
+        return GSS_OK;
+    };
+    auto estep = [&](EmBlock &b, int mode) -> int {
+        EmArgs &a = b.a;
+        if (reg && mode != MODE_FIRST) {
+            a.Sg = b.Sg_reg;
+            switch (D) {
+                case 24: return launch_estep_reg_k<24>(ctx, K, mode, a, b.Mq, b.Yn, b.F);
+                case 20: return launch_estep_reg_k<20>(ctx, K, mode, a, b.Mq, b.Yn, b.F);
+                case 12: return launch_estep_reg_k<12>(ctx, K, mode, a, b.Mq, b.Yn, b.F);
+                case 10: return launch_estep_reg_k<10>(ctx, K, mode, a, b.Mq, b.Yn, b.F);
+                default: return launch_estep_reg_k<4>(ctx, K, mode, a, b.Mq, b.Yn, b.F);
+            }
+        }
+        a.Sg = b.Sg_lds;
+        return launch_estep_k(ctx, K, mode, a, b.Mq, b.F);
+    };
+    auto eig = [&](EmBlock &b) -> int {
+        EmArgs &a = b.a;
         {
             GSS_PROF(ctx, "em_chol");
             const int nr = (D + 7) / 8;
             const size_t lds = sizeof(cplx) * (size_t)D * (8 * nr + 1) + sizeof(double) * D;
             auto kern = nr <= 1 ? em_chol_kernel<1> : nr == 2 ? em_chol_kernel<2>
                         : nr == 3 ? em_chol_kernel<3> : em_chol_kernel<4>;
-            hipLaunchKernelGGL(kern, dim3(K, F), dim3(64), lds, ctx->stream, a.Bp, a.Sg, bp_nch,
-                               sg_nch, D, K, T, 1e-10, force_eigh, Mq, logdet, pi, need_eigh, tri_tab,
-                               a.mseg);
+            hipLaunchKernelGGL(kern, dim3(K, b.F), dim3(64), lds, ctx->stream, a.Bp, a.Sg, b.bp_nch,
+                               b.sg_nch, D, K, T, 1e-10, force_eigh, b.Mq,
+                               const_cast<double *>(a.logdet), const_cast<double *>(a.pi),
+                               b.need_eigh, tri_tab, a.mseg);
             GSS_LAUNCH_CHECK(ctx, "em_chol_kernel");
         }
         {
             GSS_PROF(ctx, "em_eigh");
-            hipLaunchKernelGGL(em_eigh_kernel, dim3(K, F), dim3(64), eigh_lds, ctx->stream, a.Bp,
-                               a.Sg, bp_nch, sg_nch, D, K, 1e-10, need_eigh, Mq, logdet, tri_tab, a.mseg);
+            hipLaunchKernelGGL(em_eigh_kernel, dim3(K, b.F), dim3(64), eigh_lds, ctx->stream, a.Bp,
+                               a.Sg, b.bp_nch, b.sg_nch, D, K, 1e-10, b.need_eigh, b.Mq,
+                               const_cast<double *>(a.logdet), tri_tab, a.mseg);
             GSS_LAUNCH_CHECK(ctx, "em_eigh_kernel");
         }
         return GSS_OK;
     };
 
-    // one array: the whole EM (all iterations + predict) in one launch (em_onchip4_kernel)
-    if (D == 4 && K >= 2 && K <= 6 && reg && iterations > 0 && !gss_variant_set("em_unfused")) {
+    if (onchip) {
+        EmBlock b;
+        GSS_TRY(make_block(0, F, ctx->stream, &b));
+        GSS_TRY(prepare(b));
         OnchipArgs o{};
         o.Mq = Mq;
         o.Yn = Yn;
@@ -2111,28 +2224,60 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     }
 
     // CACGMMTrainer.fit(initialization=array, iterations=I, source_activity_mask)
-    auto em_iteration = [&](bool first) -> int {
-        GSS_TRY(estep(first ? MODE_FIRST : MODE_EM));
-        sg_nch = (reg && !first) ? reg_nch : nch_lds;
-        GSS_TRY(launch_mstep_k(ctx, K, a, Yn, F));
-        return eig();
+    auto em_iteration = [&](EmBlock &b, bool first) -> int {
+        GSS_TRY(estep(b, first ? MODE_FIRST : MODE_EM));
+        b.sg_nch = (reg && !first) ? b.reg_nch : b.nch_lds;
+        GSS_TRY(launch_mstep_k(ctx, K, b.a, b.Yn, b.F));
+        return eig(b);
     };
-    for (int it = 0; it < iterations; ++it) {
-        a.masked = 1;
-        a.aff_eps = 1e-10;
-        GSS_TRY(em_iteration(it == 0));
+
+    // The blocks of a group (1 or 2) advance together, launch by launch, each on its own stream.
+    hipStream_t const main_stream = ctx->stream;
+    StreamRestore restore{ctx, main_stream};
+    const int group = bplan.streams;
+    if (group > 1) {
+        GSS_TRY(aux_stream_ready(ctx));
+        GSS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, main_stream));
+        GSS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
     }
-    if (iterations_post > 1) {
+    for (int b0 = 0; b0 < bplan.nblocks; b0 += group) {
+        EmBlock blk[2];
+        const int nb = std::min(group, bplan.nblocks - b0);
+        for (int j = 0; j < nb; ++j)
+            GSS_TRY(make_block((b0 + j) * bplan.fb, em_block_size(bplan, F, b0 + j),
+                               j == 0 ? main_stream : ctx->aux_stream, &blk[j]));
+        auto each = [&](auto &&fn) -> int {
+            for (int j = 0; j < nb; ++j) {
+                ctx->stream = blk[j].stream;
+                GSS_TRY(fn(blk[j]));
+            }
+            return GSS_OK;
+        };
+        GSS_TRY(each([&](EmBlock &b) { return prepare(b); }));
+        for (int it = 0; it < iterations; ++it)
+            GSS_TRY(each([&](EmBlock &b) {
+                b.a.masked = 1;
+                b.a.aff_eps = 1e-10;
+                return em_iteration(b, it == 0);
+            }));
         // fit(initialization=model, iterations=post-1): no mask, default clip
-        for (int it = 0; it < iterations_post - 1; ++it) {
-            a.masked = 0;
-            a.aff_eps = 1e-10;
-            GSS_TRY(em_iteration(false));
-        }
+        for (int it = 0; it < iterations_post - 1; ++it)
+            GSS_TRY(each([&](EmBlock &b) {
+                b.a.masked = 0;
+                b.a.aff_eps = 1e-10;
+                return em_iteration(b, false);
+            }));
+        // predict: affiliation_eps = 0; mask only when iterations_post == 0
+        GSS_TRY(each([&](EmBlock &b) {
+            b.a.masked = iterations_post == 0 ? 1 : 0;
+            b.a.aff_eps = 0.0;
+            return estep(b, MODE_PREDICT);
+        }));
     }
-    // predict: affiliation_eps = 0; mask only when iterations_post == 0
-    a.masked = iterations_post == 0 ? 1 : 0;
-    a.aff_eps = 0.0;
-    GSS_TRY(estep(MODE_PREDICT));
+    ctx->stream = main_stream;
+    if (group > 1) {
+        GSS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
+        GSS_HIP_CHECK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+    }
     return GSS_OK;
 }

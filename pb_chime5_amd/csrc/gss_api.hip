@@ -13,6 +13,11 @@
 #define GSS_ENTER(ctx)                                   \
     if (!(ctx)) return GSS_ERR_INVALID;                  \
     GSS_HIP_CHECK((ctx), hipSetDevice((ctx)->device))
+// entry points whose kernels have GSS_VARIANT switches (WPE, EM, the fused pipeline)
+#define GSS_ENTER_VARIANTS(ctx) \
+    GSS_ENTER(ctx);             \
+    GSS_TRY(variant_refresh(ctx))
+static int variant_refresh(gss_ctx *ctx);
 
 // ------------------------------------------------------------------ errors
 // (gss_host_malloc / gss_host_free are documented as callable from any thread -- the session
@@ -44,7 +49,8 @@ const char *const kVariantKeys[] = {
     "apply_generic", "prof_detail",
     // cacgmm.hip
     "em_wgs", "estep_wpb", "estep_lds", "mstep_prefetch_d", "mstep_tiled", "mstep_plan_min_d",
-    "mstep_chunked", "mstep_slots", "force_eigh", "em_unfused"};
+    "mstep_chunked", "mstep_slots", "force_eigh", "em_unfused", "em_l3_mb", "em_l3_fit_mb",
+    "em_streams", "mstep_maxseg"};
 struct VariantTable {
     std::mutex lock;
     std::string text;
@@ -57,32 +63,47 @@ VariantTable &variant_table() {
 }
 }   // namespace
 
-int gss_variant(const char *key, int dflt) {
+// Re-read GSS_VARIANT (once per top-level call that launches variant-switched kernels -- the
+// kernels' host code below only looks at the parsed table).  An unknown key is an error of that
+// call, not an abort() of the host process.  The text may only be changed while no library call
+// is in flight: getenv() beside a concurrent setenv() is undefined behaviour in glibc.
+static int variant_refresh(gss_ctx *ctx) {
     const char *env = getenv("GSS_VARIANT");
     VariantTable &t = variant_table();
     std::lock_guard<std::mutex> guard(t.lock);
-    if (!t.parsed || t.text != (env ? env : "")) {
-        t.text = env ? env : "";
-        t.parsed = true;
-        t.values.clear();
-        size_t pos = 0;
-        while (pos < t.text.size()) {
-            size_t end = t.text.find_first_of(", ", pos);
-            if (end == std::string::npos) end = t.text.size();
-            const std::string tok = t.text.substr(pos, end - pos);
-            pos = end + 1;
-            if (tok.empty()) continue;
-            const size_t eq = tok.find('=');
-            const std::string name = tok.substr(0, eq);
-            bool known = false;
-            for (const char *k : kVariantKeys) known = known || name == k;
-            if (!known) {
-                fprintf(stderr, "libgss_hip: GSS_VARIANT names no switch '%s'\n", name.c_str());
-                abort();
-            }
-            t.values[name] = eq == std::string::npos ? 1 : atoi(tok.c_str() + eq + 1);
+    if (t.parsed && t.text == (env ? env : "")) return GSS_OK;
+    t.text = env ? env : "";
+    t.parsed = true;
+    t.values.clear();
+    std::string unknown;
+    size_t pos = 0;
+    while (pos < t.text.size()) {
+        size_t end = t.text.find_first_of(", ", pos);
+        if (end == std::string::npos) end = t.text.size();
+        const std::string tok = t.text.substr(pos, end - pos);
+        pos = end + 1;
+        if (tok.empty()) continue;
+        const size_t eq = tok.find('=');
+        const std::string name = tok.substr(0, eq);
+        bool known = false;
+        for (const char *k : kVariantKeys) known = known || name == k;
+        if (!known) {
+            unknown = name;
+            continue;
         }
+        t.values[name] = eq == std::string::npos ? 1 : atoi(tok.c_str() + eq + 1);
     }
+    if (!unknown.empty()) {
+        t.values.clear();
+        t.parsed = false;       // the next call reports it again
+        return gss_fail(ctx, GSS_ERR_INVALID, "GSS_VARIANT names no switch '%s'", unknown.c_str());
+    }
+    return GSS_OK;
+}
+
+int gss_variant(const char *key, int dflt) {
+    VariantTable &t = variant_table();
+    std::lock_guard<std::mutex> guard(t.lock);
     const auto it = t.values.find(key);
     return it == t.values.end() ? dflt : it->second;
 }
@@ -185,6 +206,12 @@ extern "C" int gss_destroy(gss_ctx *ctx) {
         (void)hipEventDestroy(p.stop);
     }
     for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->aux_stream) {
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamDestroy(ctx->aux_stream);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return GSS_OK;
@@ -496,7 +523,7 @@ extern "C" int gss_activity_time_to_frequency(gss_ctx *ctx, const uint8_t *act, 
 
 extern "C" int gss_wpe(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T, int D, int taps,
                        int delay, int iterations, int psd_context, gss_cplx *X) {
-    GSS_ENTER(ctx);
+    GSS_ENTER_VARIANTS(ctx);
     GSS_REQUIRE(ctx, Y && X && F >= 1 && T >= 1, GSS_ERR_INVALID, "gss_wpe: bad arguments");
     GSS_REQUIRE(ctx, D >= 1 && D <= GSS_MAX_CHANNELS, GSS_ERR_UNSUPPORTED,
                 "gss_wpe: D=%d outside [1, %d]", D, GSS_MAX_CHANNELS);
@@ -513,7 +540,7 @@ extern "C" int gss_wpe(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T, int D,
 
 extern "C" int gss_wpe_inverse_power(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T, int D,
                                      int psd_context, double *inverse_power) {
-    GSS_ENTER(ctx);
+    GSS_ENTER_VARIANTS(ctx);
     GSS_REQUIRE(ctx, Y && inverse_power && F >= 1 && T >= 1 && psd_context >= 0, GSS_ERR_INVALID,
                 "gss_wpe_inverse_power: bad arguments");
     GSS_REQUIRE(ctx, D >= 1 && D <= GSS_MAX_CHANNELS, GSS_ERR_UNSUPPORTED,
@@ -540,7 +567,7 @@ static int check_cacgmm_args(gss_ctx *ctx, int D, int K, int iterations, int pos
 extern "C" int gss_cacgmm(gss_ctx *ctx, const gss_cplx *Y, int F, int64_t T, int D,
                           const uint8_t *act, int K, int iterations, int post,
                           double *gamma) {
-    GSS_ENTER(ctx);
+    GSS_ENTER_VARIANTS(ctx);
     GSS_REQUIRE(ctx, Y && act && gamma && F >= 1 && T >= 1, GSS_ERR_INVALID,
                 "gss_cacgmm: bad arguments");
     GSS_TRY(check_cacgmm_args(ctx, D, K, iterations, post));
@@ -765,7 +792,7 @@ extern "C" int gss_enhance_observation(gss_ctx *ctx, const gss_params *p, const 
                                        int64_t N_act, int target, int64_t start_ctx,
                                        int64_t end_ctx, double *out,
                                        const gss_debug_taps *taps) {
-    GSS_ENTER(ctx);
+    GSS_ENTER_VARIANTS(ctx);
     return enhance_observation_impl(ctx, p, obs, 0, D, N, act, K, N_act, target, start_ctx, end_ctx,
                                     out, taps);
 }
@@ -775,7 +802,7 @@ extern "C" int gss_enhance_observation_pcm16(gss_ctx *ctx, const gss_params *p,
                                              const uint8_t *act, int K, int64_t N_act, int target,
                                              int64_t start_ctx, int64_t end_ctx, double *out,
                                              const gss_debug_taps *taps) {
-    GSS_ENTER(ctx);
+    GSS_ENTER_VARIANTS(ctx);
     return enhance_observation_impl(ctx, p, obs, 1, D, N, act, K, N_act, target, start_ctx, end_ctx,
                                     out, taps);
 }
@@ -785,7 +812,7 @@ extern "C" int gss_enhance_observation_host(gss_ctx *ctx, const gss_params *p,
                                             const uint8_t *act, int K, int64_t N_act,
                                             int target, int64_t start_ctx, int64_t end_ctx,
                                             double *out) {
-    GSS_ENTER(ctx);
+    GSS_ENTER_VARIANTS(ctx);
     GSS_REQUIRE(ctx, p && obs && act && out && N >= 1 && D >= 1 && K >= 1, GSS_ERR_INVALID,
                 "gss_enhance_observation_host: bad arguments");
     const int64_t T = gss_stft_num_frames(N, p->stft_size, p->stft_shift, p->stft_fading);

@@ -141,6 +141,10 @@ struct gss_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    // second stream of the frequency-blocked EM (cacgmm_run: two blocks of frequencies in
+    // flight), forked from / joined to `stream` by events; created on first use
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string error;
 
     // bump arena for intermediates of one top-level call

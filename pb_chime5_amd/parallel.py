@@ -71,13 +71,29 @@ class LocalGroup:
                 fcntl.flock(self.fd, fcntl.LOCK_UN)
         return value
 
-    def barrier(self, poll=0.0005):
+    def barrier(self, poll=0.0005, timeout=None):
+        """Wait until every rank arrived.  Ranks of a session finish minutes apart, so the
+        default limit is long (GSS_BARRIER_TIMEOUT_S, 3600 s); a launcher that died (this rank
+        re-parented) or a limit that passed raises instead of spinning forever -- the launcher
+        then terminates the remaining ranks."""
         import time
+        if timeout is None:
+            timeout = float(os.environ.get('GSS_BARRIER_TIMEOUT_S', 3600))
         self._generation += 1
         target = self._generation * self.world
         self.add(0, 1)
+        parent = os.getppid()
+        deadline = time.monotonic() + timeout
+        spins = 0
         while int(self._v[0]) < target:
             time.sleep(poll)
+            spins += 1
+            if spins % 2000 == 0:
+                if os.getppid() != parent:
+                    raise RuntimeError('LocalGroup.barrier: the launcher is gone')
+                if time.monotonic() > deadline:
+                    raise RuntimeError(f'LocalGroup.barrier: {int(self._v[0])} of {target} arrivals '
+                                       f'after {timeout:.0f} s (GSS_BARRIER_TIMEOUT_S)')
 
     def broadcast(self, obj, is_source):
         """Rank 0's picklable `obj` for every rank (dlp_mpi.bcast): a side file next to the
@@ -143,7 +159,16 @@ def init(backend=None):
     """Join the process group of the launcher.  Only host-side rendezvous, barriers and
     the work counter use it, so gloo always suffices and is the default; nccl (= RCCL) on
     request (`backend='nccl'` / GSS_DIST_BACKEND=nccl).  On a node with fewer GPUs than ranks
-    the ranks share devices (device = LOCAL_RANK % device count)."""
+    the ranks share devices (`_capi.pick_device`: distinct physical packages first).
+
+    Side effect: the calling thread (and every thread it starts afterwards) is bound to the
+    CPUs of its GPU's NUMA node (`bind_to_gpu_numa`; GSS_NUMA_BIND=0 leaves the affinity
+    alone; skipped when ranks share GPUs).  Threads the HIP runtime started while the GPU's PCI
+    address was looked up keep the full mask."""
+    if world_size() > 1:
+        # ROCr reads it when it initialises, i.e. at the first HIP call below (the host driver
+        # only supports dmabuf IPC; the launchers export it, a hand-made environment may not)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     bind_to_gpu_numa()       # (a single rank also wants its threads on its GPU's socket)
     if world_size() == 1:
         return None
@@ -159,20 +184,19 @@ def init(backend=None):
             # not depend on RCCL coming up on the node (GSS_DIST_BACKEND=nccl selects it)
             backend = 'gloo'
         if backend == 'nccl':
-            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
             torch.cuda.set_device(device_index())
         dist.init_process_group(backend=backend)
     return dist
 
 
 def _local_group():
-    """The launcher's counter file, if this rank was started by `launch_local`."""
+    """The launcher's counter file, if this rank was started by `launch_local`.  A rank that
+    cannot open the file it was given must fail (the launcher then stops the job): falling back
+    to static sharding alone, beside ranks that share the counter, would process utterances
+    twice and leave the others waiting in a barrier."""
     if _STATE['local'] is None:
         path = os.environ.get('GSS_LOCAL_GROUP')
-        try:
-            _STATE['local'] = LocalGroup(path, world_size()) if path and world_size() > 1 else False
-        except OSError:
-            _STATE['local'] = False
+        _STATE['local'] = LocalGroup(path, world_size()) if path and world_size() > 1 else False
     return _STATE['local'] or None
 
 
@@ -223,7 +247,10 @@ def shard_indices(num_items, costs=None, rank_=None, world=None):
 
 
 def split_managed(sequence, costs=None, dynamic=True):
-    """Yield the items of ``sequence`` this process should handle."""
+    """Yield the items of ``sequence`` this process should handle.  The generator ends without
+    a barrier (a consumer that prefetches -- the session driver's loader threads -- would sit
+    in it while it still holds prepared and enqueued utterances): callers synchronise after
+    their own pipeline has drained (`Enhancer.enhance_session` ends with `parallel.barrier()`)."""
     items = list(sequence) if not hasattr(sequence, '__getitem__') else sequence
     n = len(items)
     world = world_size()
@@ -257,7 +284,61 @@ def split_managed(sequence, costs=None, dynamic=True):
         if pos >= n:
             break
         yield items[order[pos]]
-    barrier()
+
+
+# ------------------------------------------------------------------ timed regions
+class RankTimer:
+    """The barriers and reductions a multi-rank measurement puts around its timed region
+    (bench.py: `barrier(); t0; work; barrier(); wall = max over ranks`): ranks finish at
+    different times -- the slowest rank's clock is the job's.  `dist` is the joined
+    torch.distributed module (None: a single rank), `group` / `device` an optional second group
+    for the reductions (an RCCL sub-group on 'cuda'); `sync` waits for this rank's GPU work."""
+
+    def __init__(self, dist=None, group=None, device='cpu', sync=None):
+        self.dist, self.group, self.device = dist, group, device
+        self.sync = sync or (lambda: None)
+
+    def barrier(self):
+        self.sync()
+        if self.dist is not None:
+            if self.group is not None:
+                self.dist.barrier(group=self.group)
+            self.dist.barrier()
+        self.sync()
+
+    def _reduce(self, x, op):
+        if self.dist is None:
+            return float(x)
+        import torch
+        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op), group=self.group)
+        return float(t.item())
+
+    def max(self, x):
+        return self._reduce(x, 'MAX')
+
+    def sum(self, x):
+        return self._reduce(x, 'SUM')
+
+    def gather(self, values):
+        """[values of rank 0, values of rank 1, ...] (a short list of floats per rank)."""
+        if self.dist is None:
+            return [list(map(float, values))]
+        import torch
+        t = torch.zeros((world_size(), len(values)), dtype=torch.float64, device=self.device)
+        t[rank()] = torch.tensor(list(values), dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().tolist()
+
+
+def scaling_rows(value, n_gpus, n1_value=None):
+    """What a SCALE record needs from an N-GPU line to describe itself: the per-GPU figure
+    and, given the N = 1 figure of the same workload, the scaling efficiency."""
+    rows = {'value_per_gpu': value / max(n_gpus, 1)}
+    if n1_value:
+        rows['n1_value'] = float(n1_value)
+        rows['scaling_efficiency_vs_n1'] = value / (n_gpus * float(n1_value))
+    return rows
 
 
 # ------------------------------------------------------------------ CPU placement
@@ -307,15 +388,22 @@ def bind_to_gpu_numa(device=None, force=False):
     exists: they inherit the mask -- to the CPUs of its GPU's NUMA node (intersected with the
     CPUs the process may use at all).  Eight ranks x (3 loaders + feeder + writer) threads
     floating over two sockets put page-locked staging blocks on the far socket: H2D / D2H
-    through the inter-socket link.  GSS_NUMA_BIND=0 switches it off.  Returns (and keeps for
-    `affinity_info`) what was done; never raises."""
+    through the inter-socket link.  GSS_NUMA_BIND=0 switches it off; so do more node-local
+    ranks than GPUs (ranks sharing a GPU would all be squeezed onto its socket).  Only the
+    calling thread and its future children move: threads the HIP runtime created during the
+    PCI lookup keep their mask, and an application embedding the package gets its calling
+    thread's affinity changed -- GSS_NUMA_BIND=0 is the switch for that.  Returns (and keeps
+    for `affinity_info`) what was done; never raises."""
     if _STATE['affinity'] is not None and not force:
         return _STATE['affinity']
     info = {'bound': False, 'numa_node': None, 'cpus': None}
     try:
         allowed = os.sched_getaffinity(0)
         info['cpus'] = _format_cpulist(allowed)
-        if os.environ.get('GSS_NUMA_BIND', '1') != '0':
+        from pb_chime5_amd import _capi
+        sharing = int(os.environ.get('LOCAL_WORLD_SIZE', world_size())) > max(_capi.device_count(), 1)
+        info['ranks_share_gpus'] = sharing
+        if os.environ.get('GSS_NUMA_BIND', '1') != '0' and not sharing:
             node, cpus = gpu_numa_cpus(device_index() if device is None else device)
             info['numa_node'] = node
             if cpus is not None and (allowed & cpus) and (allowed & cpus) != allowed:

@@ -161,3 +161,55 @@ def roofline_entry(name, avg_ms, **size):
                        'full matrix) and can exceed 1; frac_executed prices the flops the kernel '
                        'issues (tile-granularity waste included)')
     return out
+
+
+def utterance_flops(*, F, T, D, K, taps, N, wpe_iterations=3, iterations=20, wpe=True,
+                    executed=True):
+    """Real float64 operations the pipeline EXECUTES for one utterance (the sum of
+    `executed_flops`, else `flops`, of `kernel_work` over the launches of one step): what the
+    whole step is priced with against the chip's f64 peak (`f64_peak_frac` of the bench line).
+    Kernels without a flop model (activity, masks, layout) do not count."""
+    size = dict(F=F, T=T, D=D, K=K, taps=taps, N=N, iterations=iterations)
+
+    def fl(name):
+        w = kernel_work(name, **size)
+        return w.get('executed_flops', w['flops']) if executed else w['flops']
+    total = fl('stft') + fl('istft_frames') + fl('psd') + fl('mvdr_apply')
+    if wpe:
+        total += wpe_iterations * (fl('wpe_power') + fl('wpe_corr') + fl('wpe_solve') + fl('wpe_apply'))
+    if D == 4 and 2 <= K <= 6:
+        total += fl('em_onchip')
+    else:
+        total += iterations * (fl('em_estep') + fl('em_mstep') + fl('em_chol')) + fl('em_predict')
+    return total
+
+
+def step_peak_frac(ms_per_step, **shape):
+    """{'executed_gflop_per_step', 'frac', ...}: executed flops of a step / its duration / f64
+    peak; `frac_min_flops` prices the minimum of the formulation instead (no tile-granularity
+    waste: with one array the 40 unknowns on 16 x 16 MFMA tiles execute 1.57 x the products)."""
+    flops = utterance_flops(**shape)
+    least = utterance_flops(executed=False, **shape)
+    sec = ms_per_step * 1e-3
+    return {'executed_gflop_per_step': flops / 1e9,
+            'frac': flops / sec / 1e12 / PEAK_F64_TFLOPS,
+            'min_gflop_per_step': least / 1e9,
+            'frac_min_flops': least / sec / 1e12 / PEAK_F64_TFLOPS,
+            'peak_tflops': PEAK_F64_TFLOPS}
+
+
+# Which translation unit (plus the shared headers) a kernel label of the bench line lives in:
+# a PMC traffic figure is valid for the library whose sources hash the same.
+def kernel_sources(label):
+    unit = ('wpe.hip' if label.startswith('wpe_') else
+            'cacgmm.hip' if label.startswith('em_') else
+            'stft.hip' if label.startswith(('stft', 'istft', 'activity')) else 'mvdr.hip')
+    return [unit, 'gss_internal.h', 'dense_wave.h']
+
+
+def source_hashes():
+    import hashlib
+    from pathlib import Path
+    csrc = Path(__file__).resolve().parent / 'csrc'
+    return {p.name: hashlib.sha256(p.read_bytes()).hexdigest()[:16]
+            for p in sorted(csrc.iterdir()) if p.suffix in ('.hip', '.h')}

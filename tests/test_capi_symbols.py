@@ -123,3 +123,25 @@ def test_variant_keys_are_documented_and_used():
     section = doc[doc.index('## Debug switches'):doc.index('## Replacing `mpiexec')]
     documented = set(re.findall(r'`([a-z0-9_]+)(?:=[^`]*)?`', section)) & (accepted | used)
     assert documented == accepted, sorted(accepted - documented)
+
+
+def test_step_flops_and_traffic_provenance(tmp_path):
+    """bench.py's bookkeeping: the executed flops of a whole step (the `f64_peak_frac` of the
+    line: 0.58 at the headline's 14 ms, the figure the round-5 review computed by hand as 0.59)
+    and the provenance stamp of a PMC traffic file (source hashes of the dominant kernel's
+    translation unit: a stale figure must not travel inside a fresh line)."""
+    from pb_chime5_amd import roofline
+    shape = dict(F=513, T=941, D=24, K=5, taps=10, N=240000)
+    r = roofline.step_peak_frac(14.0, **shape)
+    assert 600 < r['executed_gflop_per_step'] < 680 and 0.55 < r['frac'] < 0.62
+    assert r['min_gflop_per_step'] < r['executed_gflop_per_step']
+    # the dominant kernel dominates the count, as it dominates the step
+    corr = roofline.kernel_work('wpe_corr', **shape)
+    assert 0.45 < 3 * corr['executed_flops'] / (r['executed_gflop_per_step'] * 1e9) < 0.6
+    one = roofline.step_peak_frac(2.3, F=513, T=2169, D=4, K=5, taps=10, N=554490)
+    assert one['frac_min_flops'] < one['frac'] < 0.35
+    assert roofline.kernel_sources('wpe_corr')[0] == 'wpe.hip'
+    assert roofline.kernel_sources('em_mstep')[0] == 'cacgmm.hip'
+    assert roofline.kernel_sources('psd')[0] == 'mvdr.hip'
+    hashes = roofline.source_hashes()
+    assert {'wpe.hip', 'cacgmm.hip', 'mvdr.hip', 'stft.hip', 'gss_api.hip', 'gss_internal.h'} <= set(hashes)

@@ -740,7 +740,8 @@ def test_kernel_variants_agree(gpu_ctx, D, monkeypatch):
     application), the filter application with 1 - 4 frame phases packed into the column
     dimension, register-form vs tiled M-step (D = 4), register- vs LDS-form E-step,
     Cholesky vs eigendecomposition model update, chunked vs statically partitioned M-step, the
-    one-launch EM of one array vs three launches per iteration, the correlation kernel's forms.
+    one-launch EM of one array vs three launches per iteration, the correlation kernel's forms,
+    the EM over blocks of frequencies on one and two streams.
     Same arithmetic up to summation order."""
     from pb_chime5_amd import ops, synthetic
     # (frames per unknown and sensor noise as in test_other_channel_and_class_counts: a
@@ -769,7 +770,11 @@ def test_kernel_variants_agree(gpu_ctx, D, monkeypatch):
                     # separate launches, block-wise accumulation and pair tiles in the
                     # correlation, the general form of the filter application; two at once
                     'mstep_chunked', 'mstep_slots=100', 'em_unfused', 'corr_blocked', 'corr_ts=3',
-                    'apply_generic', 'corr_p_tiles', 'estep_lds,force_eigh,corr_ts=3'):
+                    'apply_generic', 'corr_p_tiles', 'estep_lds,force_eigh,corr_ts=3',
+                    # the EM over blocks of frequencies (long segments: Infinity-Cache
+                    # residency), one and two blocks in flight, more segments per frequency
+                    'em_l3_fit_mb=0,em_l3_mb=1,em_streams=1', 'em_l3_fit_mb=0,em_l3_mb=1,em_streams=2',
+                    'em_l3_fit_mb=0,em_l3_mb=2,em_streams=2,mstep_maxseg=16,estep_lds'):
         env = {'GSS_VARIANT': variant}
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -391,6 +391,53 @@ def test_cacgmm_one_array_kernel_equals_three_launch_path(gpu_ctx, monkeypatch, 
     assert np.max(np.abs(one - want)) < 1e-7
 
 
+@pytest.mark.parametrize('D,T,F,K,iters,post', [
+    (12, 333, 45, 5, 6, 1), (24, 200, 19, 5, 4, 0), (7, 150, 33, 3, 3, 2), (10, 260, 27, 9, 3, 1)])
+@pytest.mark.parametrize('streams', [1, 2])
+def test_cacgmm_over_blocks_of_frequencies(gpu_ctx, monkeypatch, D, T, F, K, iters, post, streams):
+    """Long segments run the EM over blocks of frequencies that stay in the Infinity Cache
+    (cacgmm_run: all iterations + predict of a block -- or of two blocks on two streams --
+    before the next).  Forced here on small inputs: blocks of 8 - 24 frequencies, a ragged last
+    block, an odd number of blocks with two in flight.  Same posteriors as the single-block run
+    up to the grouping of the M-step's partial sums, and the oracle referees both."""
+    from pb_chime5_amd import ops
+    rng = np.random.default_rng(D + T + F)
+    Y, act = _scene(rng, D, T, F, K)
+    whole = ops.cacgmm_posteriors(Y, act, iters, post, ctx=gpu_ctx)
+    per_f_mb = (16 * D + 8 * K) * T / 2 ** 20
+    for fb in (8, 16):
+        # budget for `streams` blocks of fb frequencies each
+        mb = int(np.ceil(per_f_mb * fb * streams)) + 0
+        monkeypatch.setenv('GSS_VARIANT', f'em_l3_fit_mb=0,em_l3_mb={max(mb, 1)},em_streams={streams}')
+        blocked = ops.cacgmm_posteriors(Y, act, iters, post, ctx=gpu_ctx)
+        again = ops.cacgmm_posteriors(Y, act, iters, post, ctx=gpu_ctx)
+        monkeypatch.delenv('GSS_VARIANT')
+        assert np.array_equal(blocked, again)                  # deterministic
+        assert np.max(np.abs(blocked - whole)) < 1e-9, (fb, np.max(np.abs(blocked - whole)))
+    want = oracle.gss_block(Y, act, iters, post)
+    assert np.max(np.abs(blocked - want)) < 1e-7
+    # the next call on the context (one block again) is not disturbed by the second stream
+    assert np.array_equal(ops.cacgmm_posteriors(Y, act, iters, post, ctx=gpu_ctx), whole)
+
+
+def test_unknown_variant_key_is_an_error_of_the_call(gpu_ctx, monkeypatch):
+    """GSS_VARIANT with a key the library does not know: the call that reads it fails with
+    ValueError (GSS_ERR_INVALID + message) -- a typo must not silently run the default, and a
+    shared library must not abort() its host process; the next call with a valid text works."""
+    from pb_chime5_amd import ops
+    rng = np.random.default_rng(3)
+    Y, act = _scene(rng, 5, 70, 3, 3)
+    want = ops.cacgmm_posteriors(Y, act, 2, 1, ctx=gpu_ctx)
+    monkeypatch.setenv('GSS_VARIANT', 'force_eigh,no_such_switch=3')
+    for _ in range(2):
+        with pytest.raises(ValueError, match='no_such_switch'):
+            ops.cacgmm_posteriors(Y, act, 2, 1, ctx=gpu_ctx)
+    monkeypatch.setenv('GSS_VARIANT', 'mstep_chunked')
+    assert np.max(np.abs(ops.cacgmm_posteriors(Y, act, 2, 1, ctx=gpu_ctx) - want)) < 1e-9
+    monkeypatch.delenv('GSS_VARIANT')
+    assert np.array_equal(ops.cacgmm_posteriors(Y, act, 2, 1, ctx=gpu_ctx), want)
+
+
 def test_cacgmm_class_with_fewer_frames_than_channels(gpu_ctx):
     """Found by the wide fuzz sweep (GSS_FUZZ_SEED=202 GSS_FUZZ_WIDE=1, case 220, bin 43): 29
     channels, 110 frames, and after the first iteration the noise class is left with five

@@ -231,7 +231,7 @@ def test_numa_binding_from_sysfs(tmp_path, monkeypatch):
     t = threading.Thread(target=in_thread)
     t.start()
     t.join()
-    assert out['info'] == {'bound': True, 'numa_node': 1,
+    assert out['info'] == {'bound': True, 'numa_node': 1, 'ranks_share_gpus': False,
                            'cpus': parallel._format_cpulist(local)}
     assert out['mask'] == set(local) and out['child'] == set(local)     # workers inherit it
     assert os.sched_getaffinity(0) == set(allowed)
@@ -239,9 +239,117 @@ def test_numa_binding_from_sysfs(tmp_path, monkeypatch):
     monkeypatch.setenv('GSS_NUMA_BIND', '0')
     assert parallel.bind_to_gpu_numa(0, force=True)['bound'] is False
     monkeypatch.delenv('GSS_NUMA_BIND')
+    # more node-local ranks than GPUs: the ranks share devices and would all be squeezed onto
+    # one socket -- left alone
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    monkeypatch.setattr(_capi, 'device_count', lambda: 1)
+    info = parallel.bind_to_gpu_numa(0, force=True)
+    assert info['bound'] is False and info['ranks_share_gpus'] is True
+    monkeypatch.delenv('LOCAL_WORLD_SIZE')
     monkeypatch.setattr(parallel, 'gpu_numa_cpus', lambda d: (None, None))
     assert parallel.bind_to_gpu_numa(0, force=True)['bound'] is False
     parallel._STATE['affinity'] = None
+
+
+def test_ranks_go_to_distinct_physical_gpus_first():
+    """_capi.pick_device: a node-local rank's logical device.  One logical device per package
+    (the usual 8-GPU node): rank r -> device r.  A partitioned node (CPX: 8 logical devices per
+    package, same 'domain:bus:device', the function digit -- or nothing -- apart): 8 ranks land
+    on 8 different packages, not on the 8 partitions of the first; more ranks than packages
+    wrap onto further partitions; fewer GPUs than ranks: shared, round robin."""
+    from pb_chime5_amd._capi import pick_device, pci_package
+    assert pci_package('0000:C1:00.3') == '0000:c1:00'
+    spx = [f'0000:{b:02x}:00.0' for b in (0x05, 0x15, 0x65, 0x75, 0x85, 0x95, 0xe5, 0xf5)]
+    assert [pick_device(r, spx) for r in range(8)] == list(range(8))
+    assert [pick_device(r, spx[:1]) for r in range(4)] == [0, 0, 0, 0]
+    assert [pick_device(r, spx[:2]) for r in range(5)] == [0, 1, 0, 1, 0]
+    # CPX by function digit, logical devices enumerated package by package
+    cpx = [f'{bus[:-1]}{fn}' for bus in spx for fn in range(8)]
+    picked = [pick_device(r, cpx) for r in range(8)]
+    assert picked == [0, 8, 16, 24, 32, 40, 48, 56]
+    assert len({pci_package(cpx[i]) for i in picked}) == 8
+    assert [pick_device(r, cpx) for r in (8, 9, 16, 63, 64)] == [1, 9, 2, 63, 0]
+    # CPX with one PCI address per package (partitions indistinguishable by address)
+    same = [bus for bus in spx for _ in range(8)]
+    assert [pick_device(r, same) for r in range(8)] == [0, 8, 16, 24, 32, 40, 48, 56]
+    assert pick_device(3, []) == 0
+
+
+TIMER_WORKER = textwrap.dedent('''
+    import json, os, sys, time
+    sys.path.insert(0, {repo!r})
+    from pb_chime5_amd import parallel
+    dist = parallel.init(backend='gloo')
+    timer = parallel.RankTimer(dist)
+    rank = parallel.rank()
+    timer.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.2 + 2.0 * rank)            # ranks finish 2 s apart
+    local = time.perf_counter() - t0
+    timer.barrier()
+    wall = timer.max(time.perf_counter() - t0)
+    rows = timer.gather([local, rank + 10])
+    total = timer.sum(3.0 + rank)
+    print('RESULT ' + json.dumps(dict(rank=rank, local=local, wall=wall, rows=rows, total=total)),
+          flush=True)
+    timer.barrier()
+''')
+
+
+def test_timed_region_between_barriers_with_ranks_finishing_two_seconds_apart():
+    """bench.py's timing protocol on its own (parallel.RankTimer over gloo): barrier, work,
+    barrier, MAX over ranks.  Rank 1 finishes 2 s after rank 0: both report the slow rank's
+    clock as the job's wall time, the gathered per-rank rows keep each rank's own."""
+    import json
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2',
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, '-c', TIMER_WORKER.format(repo=str(REPO))],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+    res = []
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err
+        res.append(json.loads([l for l in out.splitlines() if l.startswith('RESULT ')][0][7:]))
+    res.sort(key=lambda r: r['rank'])
+    assert res[0]['local'] < 0.5 and 2.1 < res[1]['local'] < 2.7
+    for r in res:
+        assert 2.1 < r['wall'] < 3.5 and r['wall'] >= res[1]['local']
+        assert r['total'] == 7.0
+        assert [row[1] for row in r['rows']] == [10.0, 11.0]
+        assert abs(r['rows'][0][0] - res[0]['local']) < 1e-9
+        assert abs(r['rows'][1][0] - res[1]['local']) < 1e-9
+    assert res[0]['wall'] == res[1]['wall']
+    # a single rank: plain values, no process group
+    from pb_chime5_amd import parallel
+    t = parallel.RankTimer()
+    t.barrier()
+    assert t.max(1.5) == 1.5 and t.sum(2) == 2.0 and t.gather([1, 2]) == [[1.0, 2.0]]
+    assert parallel.scaling_rows(8000.0, 8) == {'value_per_gpu': 1000.0}
+    assert parallel.scaling_rows(8000.0, 8, n1_value=1070.0)['scaling_efficiency_vs_n1'] == \
+        pytest.approx(8000.0 / (8 * 1070.0))
+
+
+def test_local_group_barrier_gives_up_and_a_bad_group_file_is_an_error(tmp_path, monkeypatch):
+    """A rank must not spin forever in the node-local barrier (the other rank died), and a rank
+    that cannot open the launcher's counter file must fail instead of falling back to static
+    sharding beside ranks that share the counter (ADVICE r5)."""
+    from pb_chime5_amd import parallel
+    from pb_chime5_amd.parallel import LocalGroup
+    path = LocalGroup.create(str(tmp_path))
+    g = LocalGroup(path, 2)
+    with pytest.raises(RuntimeError, match='1 of 2 arrivals'):
+        g.barrier(poll=0.0001, timeout=0.3)
+    g.close()
+    monkeypatch.setenv('GSS_LOCAL_GROUP', str(tmp_path / 'missing'))
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    monkeypatch.setitem(parallel._STATE, 'local', None)
+    with pytest.raises(OSError):
+        parallel._local_group()
+    monkeypatch.setitem(parallel._STATE, 'local', None)
 
 
 @pytest.mark.gpu

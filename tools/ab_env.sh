@@ -1,10 +1,11 @@
 #!/bin/bash
 # tools/ab_env.sh "ENV1=a ENV2=b" "ENV3=c" ...: bench.py --only-headline once per environment
 # setting (first argument "" = default), value + per-kernel ms/utterance side by side.
+# AB_ARGS="--workload 5" adds bench arguments (another workload); AB_STEPS: timed steps (10).
 R=$(cd "$(dirname "$0")/.." && pwd)
 i=0
 for e in "$@"; do
-  env $e python $R/bench.py --only-headline --steps 10 > /tmp/ab_$i.json 2>/tmp/ab_$i.err || tail -3 /tmp/ab_$i.err
+  env $e python $R/bench.py --only-headline --steps ${AB_STEPS:-10} $AB_ARGS > /tmp/ab_$i.json 2>/tmp/ab_$i.err || tail -3 /tmp/ab_$i.err
   i=$((i+1))
 done
 python - "$@" <<'PY'

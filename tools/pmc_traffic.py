@@ -60,8 +60,17 @@ def main():
         f = 2.0 * 1024.0 * fetch.get(k, 0.0)
         w = 1024.0 * write.get(k, 0.0)
         res[k] = {'fetch_bytes': f, 'write_bytes': w, 'bytes': f + w}
+    # what the counters were taken on: bench.py drops `roofline.traffic` (marks it stale) when
+    # the sources of the dominant kernel's translation unit hash differently
+    import os
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from pb_chime5_amd import roofline
+    res['__meta__'] = {'source_hashes': roofline.source_hashes(),
+                       'gss_variant': os.environ.get('GSS_VARIANT', '')}
     json.dump(res, open(out, 'w'), indent=1)
-    for k, v in sorted(res.items(), key=lambda kv: -kv[1]['bytes'])[:12]:
+    for k, v in sorted(((k, v) for k, v in res.items() if k != '__meta__'),
+                       key=lambda kv: -kv[1]['bytes'])[:12]:
         print(f"{k:18s} fetch {v['fetch_bytes']/1e6:9.1f} MB  write {v['write_bytes']/1e6:9.1f} MB per launch")
 
 
