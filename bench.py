@@ -581,6 +581,11 @@ def parse_args():
     ap.add_argument('--session-seconds', type=float, default=660.0,
                     help='config 4s: length of the synthetic dev-shaped session')
     ap.add_argument('--session-utterances', type=int, default=220)
+    ap.add_argument('--sessions', default='S02,S09',
+                    help="config 4s: the sessions of the stand-in corpus; the default is what "
+                         "`session_id=dev` resolves to (scripts/run.py:45-71): S02 (6 arrays = 24 ch) "
+                         "and S09 (5 arrays = 20 ch, mapping.py:67), --session-seconds and "
+                         "--session-utterances split evenly between them")
     ap.add_argument('--loaders', type=int, default=3, help='config 4s: loader threads per rank')
     ap.add_argument('--no-config4s', action='store_true')
     ap.add_argument('--multiarray', default='True', choices=('True', 'False', 'outer_array_mics'),
@@ -807,7 +812,8 @@ def main():
         import shutil
         import tempfile
         from pb_chime5_amd.core import get_enhancer
-        from pb_chime5_amd.synthetic_corpus import write_dev_shaped_session
+        from pb_chime5_amd.synthetic_corpus import write_dev_shaped_corpus
+        sessions = [x for x in args.sessions.split(',') if x]
         base = os.environ.get('GSS_BENCH_SCRATCH')
         if base is None:
             shm = Path('/dev/shm')
@@ -818,8 +824,9 @@ def main():
         t_gen = time.perf_counter()
         if rank == 0:
             shutil.rmtree(root, ignore_errors=True)
-            write_dev_shaped_session(root / 'corpus', seconds=args.session_seconds,
-                                     num_utterances=args.session_utterances)
+            write_dev_shaped_corpus(root / 'corpus', sessions,
+                                    seconds=args.session_seconds / len(sessions),
+                                    num_utterances=args.session_utterances // len(sessions))
         barrier()
         t_gen = time.perf_counter() - t_gen
         json_path = root / 'corpus' / 'chime5.json'
@@ -835,15 +842,19 @@ def main():
             # JSON parse, activity tracks from the annotations, file opens are in the wall clock
             warm = get_enhancer(**kw)
             warm.inflight, warm.loaders = args.inflight, args.loaders
-            examples = sorted(warm.get_iterator('S02'), key=obs_samples)
+            examples = sorted(warm.get_iterator(sessions), key=obs_samples)
             (root / f'warm{rank}' / 'dev').mkdir(parents=True)
-            warm._enhance_and_write(examples[-(args.inflight + 1):], root / f'warm{rank}')
+            # the longest utterances of EVERY session: arenas and staging sized for both
+            # channel counts
+            warm_set = [ex for sid in sessions
+                        for ex in [e for e in examples if e['session_id'] == sid][-(args.inflight + 1):]]
+            warm._enhance_and_write(warm_set, root / f'warm{rank}')
             del warm
             enh = get_enhancer(**kw)
             enh.inflight, enh.loaders = args.inflight, args.loaders
             barrier()
             t0 = time.perf_counter()
-            enh.enhance_session('S02', root / 'out', audio_dir_exist_ok=True)
+            enh.enhance_session(sessions, root / 'out', audio_dir_exist_ok=True)
             local = time.perf_counter() - t0
             barrier()
             wall = max_over_ranks(time.perf_counter() - t0)
@@ -866,17 +877,22 @@ def main():
         if rank != 0:
             return None
         return {
-            'workload': (f'BASELINE.json configs[3] stand-in: synthetic CHiME-5-layout session S02, '
-                         f'{args.session_seconds:.0f} s x 24 per-channel PCM16 WAV files '
+            'workload': (f'BASELINE.json configs[3] stand-in: synthetic CHiME-5-layout session(s) '
+                         f'{"+".join(sessions)} (session_id=dev is S02 with 6 arrays AND S09 with 5: the '
+                         f'channel count changes mid-run), {args.session_seconds:.0f} s in all x 24 / 20 '
+                         f'per-channel PCM16 WAV files '
                          f'({in_bytes / 1e6:.0f} MB) under {base}, {len(examples)} utterances '
                          '(dev-shaped lengths, 2 x 15 s context, '
-                         + {'True': 'multiarray=True: all 6 arrays = 24 ch',
+                         + {'True': 'multiarray=True: all arrays = 24 ch (S02) / 20 ch (S09)',
                             'False': 'multiarray=False, the reference default: the reference array = 4 ch',
                             'outer_array_mics': 'multiarray=outer_array_mics: 2 microphones of each '
                                                 'of the 6 arrays = 12 ch'}[args.multiarray]
                          + ', K = 5), get_enhancer() defaults: WPE taps=10, 20 EM iterations, MVDR+BAN'),
             'multiarray': args.multiarray,
-            'driver': 'Enhancer.enhance_session(\'S02\', out) as scripts/run.py calls it',
+            'sessions': sessions,
+            'utterances_per_session': {sid: sum(ex['session_id'] == sid for ex in examples)
+                                       for sid in sessions},
+            'driver': f'Enhancer.enhance_session({sessions}, out) as scripts/run.py calls it',
             'includes': ('JSON database + annotation activity, WAV slice reads into page-locked '
                          'int16 blocks, H2D, enhancement, D2H of the trimmed utterance, peak '
                          'normalisation + PCM16 WAV writes'),

@@ -294,7 +294,7 @@ __device__ __forceinline__ void corr_zero(v4d (&t1)[TS][TS], v4d (&t2)[TS][TS], 
         }
 }
 
-template <int TS, int MASK, int NW>
+template <int TS, int MASK, int NW, int STG1 = 8>
 __device__ __forceinline__ void corr_tile_body(
     const cplx *__restrict__ Yf, const double *__restrict__ wf, int64_t T, int D, int n, int c,
     int frames_lds, cplx *S, double *wS, const CorrTile tl, bool active, int f,
@@ -310,7 +310,12 @@ __device__ __forceinline__ void corr_tile_body(
 #ifndef GSS_CORR_STG_ELEMS
 #define GSS_CORR_STG_ELEMS 2048
 #endif
-    constexpr int CORR_STG = NW == 1 ? 8 : (TS == 1 ? 1024 : GSS_CORR_STG_ELEMS) / NT;
+    // (single-wave workgroups: STG1 elements per lane -- 5 cover one array's 80-frame window of
+    // 320 elements, and the 12 registers that 8 would cost more are what lets a FOURTH wave
+    // share the SIMD: at 138 registers 3072 waves were resident and the last 6 of the
+    // 513 x 6 = 3078 ran alone in a second round -- 0.27 ms per launch of which 0.1 ms were
+    // that tail)
+    constexpr int CORR_STG = NW == 1 ? STG1 : (TS == 1 ? 1024 : GSS_CORR_STG_ELEMS) / NT;
     const int total = frames_lds * D;
     cplx stg[CORR_STG];
     double stg_w = 0.0;
@@ -349,8 +354,8 @@ __device__ __forceinline__ void corr_tile_body(
     if (active) corr_store<TS, MASK>(tl, f, n, c, D, t1, t2, t3, R, P);
 }
 
-template <int TS, int NW>
-__global__ __launch_bounds__(64 * NW) void wpe_corr_kernel(
+template <int TS, int NW, int STG1 = 8>
+__global__ __launch_bounds__(64 * NW, (NW == 1 && STG1 < 8) ? 4 : 1) void wpe_corr_kernel(
     const cplx *__restrict__ Y, const double *__restrict__ w, int F, int64_t T, int D, int n,
     int c, int padf, const CorrTile *__restrict__ tiles, int ntiles, cplx *__restrict__ R,
     cplx *__restrict__ P) {
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_kernel(
     constexpr int FULL = (1 << (TS * TS)) - 1;
     const int mask = __builtin_amdgcn_readfirstlane(active ? tl.mask : 1);
 #define CORR_CASE(M) \
-    case M: corr_tile_body<TS, M, NW>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P); break
+    case M: corr_tile_body<TS, M, NW, STG1>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P); break
     if (TS == 2) {
         switch (mask) {
             CORR_CASE(1);
@@ -378,12 +383,102 @@ __global__ __launch_bounds__(64 * NW) void wpe_corr_kernel(
             CORR_CASE(5);
             CORR_CASE(11);
             default:
-                corr_tile_body<TS, FULL, NW>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P);
+                corr_tile_body<TS, FULL, NW, STG1>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P);
         }
     } else {
-        corr_tile_body<TS, FULL, NW>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P);
+        corr_tile_body<TS, FULL, NW, STG1>(Yf, wf, T, D, n, c, frames_lds, S, wS, tl, active, f, R, P);
     }
 #undef CORR_CASE
+}
+
+// ---- few channels (one array): the waves of a workgroup split the FRAMES of one sub-tile
+// One array at 10 taps is 6 sub-tiles of 16 x 16 per frequency: 3078 single waves of 34 chunks
+// each -- 3 x 1024 + 6.  The dispatcher fills SIMDs up to their limit, so whatever the limit is
+// the launch ends on a handful of SIMDs that hold one wave more than the rest (three waves per
+// SIMD: the last six waves ran alone in a second round; four: a quarter of the chip idle while
+// the rest works through four): wave lifetime 158 us, launch 270 us (profiles/r05b_1a_*).
+// Here a workgroup is still ONE sub-tile of one frequency, but its KS waves take a quarter of
+// the 64-frame chunks each (own window in LDS, no workgroup barrier in the loop) and the
+// partial tiles are added in wave order through LDS at the end (deterministic): 12 312 waves a
+// quarter as long, handed out as slots become free -- the SIMDs stay evenly loaded and the tail
+// is a quarter-wave.  The sums are blocked (four partial sums) instead of one run over T.
+template <int KS, int STG>
+__global__ __launch_bounds__(64 * KS, 4) void wpe_corr_ksplit_kernel(
+    const cplx *__restrict__ Y, const double *__restrict__ w, int F, int64_t T, int D, int n,
+    int c, int padf, const CorrTile *__restrict__ tiles, int ntiles, cplx *__restrict__ R,
+    cplx *__restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int frames_lds = CORR_KT + c + padf;
+    const int total = frames_lds * D;                               // <= 64 * STG
+    const size_t wbytes = sizeof(cplx) * (size_t)total + sizeof(double) * CORR_KT;
+    int f, tile_id;
+    if (!xcd_group_map(ntiles, F, f, tile_id)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    cplx *S = reinterpret_cast<cplx *>(smem + wave * wbytes);
+    double *wS = reinterpret_cast<double *>(S + total);
+    const CorrTile tl = tiles[tile_id];
+    const cplx *Yf = Y + (int64_t)f * T * D;
+    const double *wf = w + (int64_t)f * T;
+    v4d t1[1][1], t2[1][1], t3[1][1];
+    corr_zero<1>(t1, t2, t3);
+
+    const int nchunk = (int)((T + CORR_KT - 1) / CORR_KT);
+    const int ch0 = (int)((int64_t)wave * nchunk / KS), ch1 = (int)((int64_t)(wave + 1) * nchunk / KS);
+    cplx stg[STG];
+    double stg_w = 0.0;
+    auto stage_load = [&](int64_t t0) {
+        const int64_t fr0 = t0 - c;
+#pragma unroll
+        for (int s = 0; s < STG; ++s) {
+            const int idx = lane + 64 * s;
+            const int64_t fr = fr0 + idx / D;
+            stg[s] = c_make(0.0, 0.0);
+            if (idx < total && fr >= 0 && fr < T) stg[s] = Yf[fr0 * D + idx];
+        }
+        stg_w = (t0 + lane < T) ? wf[t0 + lane] : 0.0;
+    };
+    if (ch0 < ch1) stage_load((int64_t)ch0 * CORR_KT);
+    for (int ch = ch0; ch < ch1; ++ch) {
+        wave_sync();              // this wave is done with the previous chunk's window
+#pragma unroll
+        for (int s = 0; s < STG; ++s) {
+            const int idx = lane + 64 * s;
+            if (idx < total) S[idx] = stg[s];
+        }
+        wS[lane] = stg_w;
+        wave_sync();
+        if (ch + 1 < ch1) stage_load((int64_t)(ch + 1) * CORR_KT);
+        corr_chunk<1, 1>(S, wS, D, tl, t1, t2, t3);
+    }
+    // re / im of this wave's partial tile; waves 1 ... KS - 1 park theirs in LDS (the windows
+    // are idle by then), wave 0 adds them in wave order and stores
+    v4d re, im;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        re[r] = t1[0][0][r] + t2[0][0][r];
+        im[r] = (t3[0][0][r] - t1[0][0][r]) + t2[0][0][r];
+    }
+    __syncthreads();
+    cplx *red = reinterpret_cast<cplx *>(smem);
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave - 1) * 4 + r) * 64 + lane] = c_make(re[r], im[r]);
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int o = 0; o < KS - 1; ++o)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const cplx v = red[(o * 4 + r) * 64 + lane];
+                re[r] += v.x;
+                im[r] += v.y;
+            }
+        t1[0][0] = re;
+        t3[0][0] = im;
+        corr_store<1, 1, true>(tl, f, n, c, D, t1, t1, t3, R, P);
+    }
 }
 
 // ---- the same tiles with the window brought in by LDS-DMA (`buffer_load_dwordx4 ... lds`)
@@ -1836,10 +1931,28 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     // one array: the window is a few KB, every wave stages its own and the hardware
     // balances single waves (no idle wave in a workgroup, no barrier partner to wait for)
     if (corr_ts == 1 && (size_t)(CORR_KT + c + padf) * D <= 512 && !nw_forced) corr_nw = 1;
-    auto corr_fn = corr_ts == 1 && corr_nw == 1 ? wpe_corr_kernel<1, 1>
+    // (single waves whose window is at most 320 elements -- one array at 10 taps -- stage 5
+    // elements per lane and fit four to a SIMD; GSS_VARIANT corr_stg8: the 8-element form)
+    const bool corr_stg5 = (size_t)(CORR_KT + c + padf) * D <= 320 && !gss_variant_set("corr_stg8");
+    auto corr_fn = corr_ts == 1 && corr_nw == 1 ? (corr_stg5 ? wpe_corr_kernel<1, 1, 5> : wpe_corr_kernel<1, 1>)
                    : corr_ts == 1 ? (corr_nw == 2 ? wpe_corr_kernel<1, 2> : wpe_corr_kernel<1, 4>)
                                   : (corr_nw == 2 ? wpe_corr_kernel<2, 2> : wpe_corr_kernel<2, 4>);
-    const size_t corr_lds = sizeof(cplx) * (size_t)(CORR_KT + c + padf) * D + sizeof(double) * CORR_KT;
+    size_t corr_lds = sizeof(cplx) * (size_t)(CORR_KT + c + padf) * D + sizeof(double) * CORR_KT;
+    // few channels, single-wave workgroups: the waves of a workgroup split the frames of one
+    // sub-tile instead (wpe_corr_ksplit_kernel; GSS_VARIANT corr_ksplit=1: single waves)
+    const int ksplit_forced = gss_variant("corr_ksplit", 0);
+    const int corr_ks = (corr_ts == 1 && corr_nw == 1 && ksplit_forced != 1)
+                            ? (ksplit_forced == 2 ? 2 : ksplit_forced == 8 ? 8 : 4) : 1;
+    using corr_fn_t = void (*)(const cplx *, const double *, int, int64_t, int, int, int, int,
+                               const CorrTile *, int, cplx *, cplx *);
+    corr_fn_t ksplit_fn = nullptr;
+    if (corr_ks > 1) {
+        ksplit_fn = corr_stg5 ? (corr_ks == 2 ? wpe_corr_ksplit_kernel<2, 5>
+                                 : corr_ks == 8 ? wpe_corr_ksplit_kernel<8, 5> : wpe_corr_ksplit_kernel<4, 5>)
+                              : (corr_ks == 2 ? wpe_corr_ksplit_kernel<2, 8>
+                                 : corr_ks == 8 ? wpe_corr_ksplit_kernel<8, 8> : wpe_corr_ksplit_kernel<4, 8>);
+        corr_lds = std::max(corr_lds * corr_ks, sizeof(cplx) * 256 * (size_t)(corr_ks - 1));
+    }
     const size_t panel_lds = sizeof(cplx) * CH_NB * UD_LD + sizeof(double) * CH_NB;
     static_assert(BS_LD <= UD_LD, "S must fit in Ud");
     constexpr int apply_ta = 2;
@@ -1967,9 +2080,13 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
             GSS_LAUNCH_CHECK(ctx, "wpe_corr_persist_kernel");
         } else {
             GSS_PROF(ctx, "wpe_corr");
-            hipLaunchKernelGGL(corr_fn, dim3(xcd_grid((ntiles + corr_nw - 1) / corr_nw, F)),
-                               dim3(64 * corr_nw), corr_lds,
-                               ctx->stream, Y, w, F, T, D, n, c, padf, tiles_dev, ntiles, R, P);
+            if (ksplit_fn)
+                hipLaunchKernelGGL(ksplit_fn, dim3(xcd_grid(ntiles, F)), dim3(64 * corr_ks), corr_lds,
+                                   ctx->stream, Y, w, F, T, D, n, c, padf, tiles_dev, ntiles, R, P);
+            else
+                hipLaunchKernelGGL(corr_fn, dim3(xcd_grid((ntiles + corr_nw - 1) / corr_nw, F)),
+                                   dim3(64 * corr_nw), corr_lds,
+                                   ctx->stream, Y, w, F, T, D, n, c, padf, tiles_dev, ntiles, R, P);
             GSS_LAUNCH_CHECK(ctx, "wpe_corr_kernel");
         }
         {

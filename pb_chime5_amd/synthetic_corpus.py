@@ -36,7 +36,22 @@ def write_chime5_corpus(root, session_id='S02', seconds=10.0, seed=11, utts_per_
     """Writes ``root/audio/<dataset>/<session>_<array>.CH<m>.wav`` and
     ``root/chime5.json``; returns the path of the JSON.  ``chime6=True`` writes the
     CHiME-6 flavour instead (``root/chime6.json``): one synchronised clock, so start /
-    end / num_samples are plain integers (create_json.py:361-363,436-439)."""
+    end / num_samples are plain integers (create_json.py:361-363,436-439).
+    ``session_id`` may be a list (``['S02', 'S09']`` = the dev set: S09 has five arrays,
+    mapping.py:67): every session gets its own audio (seed + its position in the list) and
+    ONE database holds them all, ``alias`` dev -> both, as create_json writes it."""
+    if not isinstance(session_id, str):
+        sessions = {}
+        for i, sid in enumerate(session_id):
+            sessions[sid] = _write_chime5_session(root, sid, seconds, seed + i, utts_per_speaker,
+                                                  num_redacted, rir_taps, chime6)
+        return _write_database(root, sessions, chime6)
+    return _write_database(root, {session_id: _write_chime5_session(
+        root, session_id, seconds, seed, utts_per_speaker, num_redacted, rir_taps, chime6)}, chime6)
+
+
+def _write_chime5_session(root, session_id, seconds, seed, utts_per_speaker, num_redacted,
+                          rir_taps, chime6):
     from scipy.signal import fftconvolve
     root = Path(root)
     rng = np.random.default_rng(seed)
@@ -76,14 +91,13 @@ def write_chime5_corpus(root, session_id='S02', seconds=10.0, seed=11, utts_per_
     for d, (a, m) in enumerate(channels):
         dump_audio(obs[d], audio_dir / f'{session_id}_{a}.CH{m}.wav', normalize=False)
 
-    return _write_json(root, rng, session_id, utterances, n_total, audio_dir, chime6)
+    return _session_examples(rng, session_id, utterances, n_total, audio_dir, chime6)
 
 
-def _write_json(root, rng, session_id, utterances, n_total, audio_dir, chime6):
-    """The example JSON for `utterances` [(speaker, start, end, words) on the 'original' clock]:
-    per-array / per-worn-microphone clocks with an offset and a per-utterance jitter."""
-    root = Path(root)
-    dataset = mapping.session_to_dataset[session_id]
+def _session_examples(rng, session_id, utterances, n_total, audio_dir, chime6):
+    """The examples of one session for `utterances` [(speaker, start, end, words) on the
+    'original' clock]: per-array / per-worn-microphone clocks with an offset and a
+    per-utterance jitter."""
     speakers = mapping.session_to_speakers[session_id]
     arrays = mapping.session_to_arrays[session_id]
     audio_path = {
@@ -127,15 +141,42 @@ def _write_json(root, rng, session_id, utterances, n_total, audio_dir, chime6):
         }
         examples[_example_id(spk, session_id, start, end, chime6)] = ex
 
-    database = {'datasets': {session_id: examples}, 'alias': {dataset: [session_id]}}
-    json_path = root / ('chime6.json' if chime6 else 'chime5.json')
+    return examples
+
+
+def _write_database(root, sessions, chime6):
+    """`sessions` {session id: examples} -> root/chime5.json (chime6.json): ``datasets`` keyed
+    by session, ``alias`` dataset -> its sessions (create_json.py:306-475)."""
+    alias = {}
+    for session_id in sessions:
+        alias.setdefault(mapping.session_to_dataset[session_id], []).append(session_id)
+    database = {'datasets': dict(sessions), 'alias': alias}
+    json_path = Path(root) / ('chime6.json' if chime6 else 'chime5.json')
     with open(json_path, 'w') as fd:
         json.dump(database, fd, indent=1, sort_keys=True)
     return json_path
 
 
+def _write_json(root, rng, session_id, utterances, n_total, audio_dir, chime6):
+    return _write_database(root, {session_id: _session_examples(
+        rng, session_id, utterances, n_total, audio_dir, chime6)}, chime6)
+
+
+def write_dev_shaped_corpus(root, session_ids=('S02', 'S09'), seconds=660.0, num_utterances=220,
+                            seed=4, rir_taps=512):
+    """`write_dev_shaped_session` for several sessions behind ONE database: ``session_id=dev``
+    of the reference's scripts is S02 (6 arrays = 24 channels) AND S09 (5 arrays = 20 channels,
+    mapping.py:67) -- the channel count changes in the middle of a run.  `num_utterances` and
+    `seconds` per session."""
+    sessions = {}
+    for i, sid in enumerate(session_ids):
+        sessions[sid] = write_dev_shaped_session(root, sid, seconds, num_utterances, seed + i,
+                                                 rir_taps, database=False)
+    return _write_database(root, sessions, False)
+
+
 def write_dev_shaped_session(root, session_id='S02', seconds=660.0, num_utterances=220, seed=4,
-                             rir_taps=512, block=1 << 18):
+                             rir_taps=512, block=1 << 18, database=True):
     """A session at the size the CHiME-5 dev set has per utterance (BASELINE.json configs[3]
     stand-in; the corpus itself is not available): 6 arrays x 4 per-channel PCM16 files of
     `seconds` of audio, `num_utterances` utterances whose lengths follow the dev-shaped draw of
@@ -188,4 +229,5 @@ def write_dev_shaped_session(root, session_id='S02', seconds=660.0, num_utteranc
         pcm[:, b0:b0 + nb] = np.clip(np.rint(y * (0.03 * 32768)), -32768, 32767)
     for d, (a, m) in enumerate(channels):
         dump_audio(pcm[d], audio_dir / f'{session_id}_{a}.CH{m}.wav', normalize=False)
-    return _write_json(root, rng, session_id, utterances, n_total, audio_dir, False)
+    examples = _session_examples(rng, session_id, utterances, n_total, audio_dir, False)
+    return _write_database(root, {session_id: examples}, False) if database else examples

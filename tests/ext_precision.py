@@ -150,3 +150,126 @@ def beamformer_all_bins(Obs, target_mask, distortion_mask, ref_channel, bf='mvdr
              np.ascontiguousarray(distortion_mask[:, f]), ref_channel, bf) for f in range(F)]
     with ProcessPoolExecutor(workers, mp_context=mp.get_context('spawn')) as ex:
         return np.array(list(ex.map(_bin_job, jobs, chunksize=8))).T
+
+
+# ---------------------------------------------------------------- guided CACGMM EM
+def eigh(A, max_sweeps=60):
+    """Eigendecomposition of one Hermitian matrix in extended precision by cyclic Jacobi
+    (numpy.linalg has no longdouble path): eigenvalues (n,) longdouble, eigenvectors as the
+    columns of V (n, n) clongdouble.  Pairs are rotated until every off-diagonal entry is below
+    eps_longdouble of the larger of its two diagonal entries (or of 1e-30 of the largest
+    diagonal entry: pairs inside the rounding noise of the matrix)."""
+    A = np.array(A, dtype=CLD)
+    n = A.shape[0]
+    A = (A + A.conj().T) / 2
+    V = np.eye(n, dtype=CLD)
+    eps = np.finfo(LD).eps
+    for _ in range(max_sweeps):
+        d = np.abs(A.diagonal().real)
+        scale = np.maximum(np.maximum(d[:, None], d[None, :]), LD(1e-30) * max(d.max(), LD(1e-300)))
+        off = np.abs(A) / scale
+        np.fill_diagonal(off, 0)
+        if off.max() <= 4 * eps:
+            break
+        for p in range(n - 1):
+            for q in range(p + 1, n):
+                b = A[p, q]
+                babs = np.abs(b)
+                if babs == 0:
+                    continue
+                tau = (A[q, q].real - A[p, p].real) / (2 * babs)
+                t = (LD(1) if tau >= 0 else LD(-1)) / (np.abs(tau) + np.sqrt(1 + tau * tau))
+                c = 1 / np.sqrt(1 + t * t)
+                s = (t * c) * (b / babs)
+                for M in (A, V):                       # columns: M <- M J
+                    mp, mq = M[:, p].copy(), M[:, q].copy()
+                    M[:, p] = c * mp - np.conj(s) * mq
+                    M[:, q] = s * mp + c * mq
+                ap, aq = A[p, :].copy(), A[q, :].copy()   # rows: A <- J^H A
+                A[p, :] = c * ap - s * aq
+                A[q, :] = np.conj(s) * ap + c * aq
+                A[p, q] = A[q, p] = 0
+                A[p, p], A[q, q] = A[p, p].real, A[q, q].real
+    return A.diagonal().real.copy(), V
+
+
+def guided_em(obs, activity, iterations, iterations_post=1):
+    """GSS.__call__ (/root/reference/pb_chime5/core.py:154-214: CACGMMTrainer.fit guided by the
+    activity, fit without the mask for iterations_post - 1, predict) for ONE frequency in 80-bit
+    extended precision: obs (T, D) complex128, activity (K, T) bool -> posteriors (K, T) float64.
+    Same formulas as the float64 implementations -- unit-norm observation, gamma / max(q, 10 tiny)
+    weights, D sum / max(sum gamma, tiny), eigenvalues / max floored at 1e-10, clip 1e-10 in fit
+    and none in predict -- with ~3 more decimal digits and its own eigensolver: the referee for
+    EM runs that hinge on the floor (classes with fewer active frames than channels), where two
+    float64 programs drift apart by more than either is off the exact iteration."""
+    tiny = LD(np.finfo(np.float64).tiny)
+    obs = np.asarray(obs)
+    T, D = obs.shape
+    activity = np.asarray(activity, bool)
+    K = activity.shape[0]
+    y = obs.astype(CLD)
+    nrm = np.sqrt(np.sum(y.real ** 2 + y.imag ** 2, axis=1))
+    y = y / np.where(nrm == 0, tiny, nrm)[:, None]                       # (T, D)
+
+    def m_step(gamma, quad):
+        model = []
+        for k in range(K):
+            wgt = gamma[k] / np.maximum(quad[k], 10 * tiny)
+            B = (y * wgt[:, None]).T @ y.conj()                            # sum_t w y y^H
+            B = B * (LD(D) / max(gamma[k].sum(), tiny))
+            lam, V = eigh(B)
+            lam = np.maximum(lam / max(lam.max(), tiny), LD(1e-10))
+            model.append((lam, V, gamma[k].sum() / LD(T)))
+        return model
+
+    def e_step(model, mask, clip):
+        lp = np.zeros((K, T), LD)
+        quad = np.zeros((K, T), LD)
+        pis = np.zeros(K, LD)
+        for k, (lam, V, pi) in enumerate(model):
+            proj = y.conj() @ V                                            # (T, D): conj(v_j^H y_t)
+            quad[k] = np.maximum(np.abs(np.sum((proj.real ** 2 + proj.imag ** 2) / lam[None, :],
+                                               axis=1)), tiny)
+            lp[k] = -LD(D) * np.log(quad[k]) - np.sum(np.log(lam))
+            pis[k] = pi
+        g = np.exp(lp - lp.max(axis=0)) * pis[:, None]
+        if mask is not None:
+            g = g * mask
+        g = g / np.maximum(g.sum(axis=0), tiny)
+        if clip:
+            g = np.clip(g, LD(clip), 1 - LD(clip))
+        return g, quad
+
+    gamma = np.where(activity, LD(1), LD(1e-10))
+    gamma = gamma / gamma.sum(axis=0)
+    quad = np.ones((K, T), LD)
+    model = None
+    for _ in range(iterations):
+        if model is not None:
+            gamma, quad = e_step(model, activity, 1e-10)
+        model = m_step(gamma, quad)
+    for _ in range(max(iterations_post - 1, 0)):
+        gamma, quad = e_step(model, None, 1e-10)
+        model = m_step(gamma, quad)
+    return e_step(model, activity if iterations_post == 0 else None, 0)[0].astype(np.float64)
+
+
+def em_yardstick(obs_f, activity, iterations, iterations_post, oracle_posteriors, referee, draws=4):
+    """What the reference's own float64 arithmetic leaves undecided for one frequency of a
+    guided EM: the larger of (oracle - referee) and the oracle's movement when every input
+    sample is changed in its last bit (`draws` random sign patterns).  pb_bss forms
+    B^-1 = V diag(1 / lambda) V^H explicitly; with eigenvalues on the 1e-10 floor its entries are
+    1e10 and q = y^H B^-1 y cancels to 1e10 eps = 1e-6: one float64 run (the oracle) is ONE
+    sample of that noise and may happen to land 1e-9 from the exact iteration where the next
+    one lands 5e-7 away.  obs_f (D, T, 1) complex128; returns the yardstick (a float)."""
+    import gss_oracle as oracle
+    rng = np.random.default_rng(20260929)
+    eps = np.finfo(np.float64).eps
+    d = float(np.max(np.abs(oracle_posteriors - referee)))
+    for _ in range(draws):
+        pert = obs_f.real * (1 + eps * rng.choice([-1.0, 1.0], size=obs_f.shape)) \
+            + 1j * obs_f.imag * (1 + eps * rng.choice([-1.0, 1.0], size=obs_f.shape))
+        moved = oracle.gss_block_batched(pert, activity, iterations=iterations,
+                                         iterations_post=iterations_post)[..., 0]
+        d = max(d, float(np.max(np.abs(moved - oracle_posteriors))))
+    return d

@@ -19,7 +19,10 @@ this file.  The reference's static table of recording lengths is pointed at the
 synthetic recordings' length (it only bounds the activity tracks).
 
 Output: chime5_session.json / chime6_session.json (bookkeeping, bit exact) and
-chime5_session.npz / chime6_session.npz (enhanced signals).  Usage:  python tests/golden/make_golden_session.py
+chime5_session.npz / chime6_session.npz (enhanced signals), and chime5_dev_sessions.{json,npz}:
+the same for ``session_id=dev`` = S02 (6 arrays) AND S09 (5 arrays, mapping.py:67) behind one
+database -- the iterator over both sessions, the activity of each, examples enhanced with
+``multiarray=True`` (24 and 20 channels).  Usage:  python tests/golden/make_golden_session.py
 """
 import copy
 import hashlib
@@ -40,6 +43,10 @@ CORPUS = dict(session_id='S02', seconds=9.0, seed=11, utts_per_speaker=2, num_re
 ENHANCER = dict(context_samples=16000, multiarray='outer_array_mics', wpe=True, wpe_tabs=4,
                 wpe_iterations=2, bss_iterations=5)
 EXAMPLES = (0, 5)
+DEV_CORPUS = dict(session_id=['S02', 'S09'], seconds=7.0, seed=23, utts_per_speaker=1, num_redacted=1)
+DEV_ENHANCER = dict(context_samples=12000, multiarray=True, wpe=True, wpe_tabs=2,
+                    wpe_iterations=2, bss_iterations=4)
+DEV_EXAMPLES = (1, 6)          # one of S02 (24 channels), one of S09 (20 channels)
 
 
 # ---------------------------------------------------------------- stand-ins
@@ -136,6 +143,43 @@ def corpus_digest(root):
     return h.hexdigest()
 
 
+def run_dev_sessions(core_module, json_path, name):
+    """``session_id=dev``: both sessions through ONE Enhancer, as scripts/run.py:45-71 +
+    core.py:333-394 do it."""
+    import pb_chime5.mapping as ref_mapping
+    sessions = DEV_CORPUS['session_id']
+    n_total = int(DEV_CORPUS['seconds'] * 16000)
+    for key in list(ref_mapping.session_array_to_num_samples):
+        if key.split('_')[0] in sessions:
+            ref_mapping.session_array_to_num_samples[key] = n_total
+    enh = core_module.get_enhancer(database_path=str(json_path), **DEV_ENHANCER)
+    it = enh.get_iterator(sessions)
+    keys = ('start', 'end', 'num_samples', 'start_orig', 'end_orig', 'num_samples_orig')
+    examples = [{'example_id': ex['example_id'], 'speaker_id': ex['speaker_id'],
+                 'session_id': ex['session_id'], 'reference_array': ex['reference_array'],
+                 **{k: _tree(ex[k]) for k in keys}} for ex in it]
+    act = {}
+    for session_id in sessions:
+        act[session_id] = {
+            array: {spk: [list(map(int, iv)) for iv in track.normalized_intervals]
+                    for spk, track in tracks.items()}
+            for array, tracks in enh.activity[session_id].items()}
+    out = {}
+    for idx in DEV_EXAMPLES:
+        ex = it[idx]
+        x_hat = enh.enhance_example(ex, debug=True)
+        loc = enh.enhance_example_locals
+        out[f'x_hat/{idx}'] = x_hat
+        out[f'obs_shape/{idx}'] = np.array(loc['obs'].shape)
+    fixture = {'corpus': {**DEV_CORPUS, 'chime6': False}, 'enhancer': DEV_ENHANCER,
+               'corpus_sha256': corpus_digest(Path(json_path).parent),
+               'examples': examples, 'activity': act, 'enhanced': list(DEV_EXAMPLES)}
+    (HERE / f'{name}.json').write_text(json.dumps(fixture, indent=1))
+    mg._save(f'{name}.npz', **out)
+    print(f'{name}.json', len(examples), 'examples of', sessions,
+          [tuple(out[f'obs_shape/{i}']) for i in DEV_EXAMPLES])
+
+
 def run_front_door(core_module, json_path, tmp, name, chime6):
     import pb_chime5.mapping as ref_mapping
     session_id = CORPUS['session_id']
@@ -187,6 +231,7 @@ def main():
         tmp = Path(tmp)
         json5 = write_chime5_corpus(tmp / 'corpus5', **CORPUS)
         json6 = write_chime5_corpus(tmp / 'corpus6', **CORPUS, chime6=True)
+        json_dev = write_chime5_corpus(tmp / 'corpus_dev', **DEV_CORPUS)
         ref = mg._prepare_reference(tmp)
         mg._register_stubs()
         mg._module('lazy_dataset', from_dict=lambda d: _Dataset(d.values()),
@@ -201,6 +246,7 @@ def main():
         import pb_chime5.core_chime6 as core_chime6
         run_front_door(core, json5, tmp, 'chime5_session', chime6=False)
         run_front_door(core_chime6, json6, tmp, 'chime6_session', chime6=True)
+        run_dev_sessions(core, json_dev, 'chime5_dev_sessions')
 
 
 if __name__ == '__main__':

@@ -313,6 +313,116 @@ def test_session_error_in_a_loader_thread_surfaces_and_does_not_hang(corpus, fix
     assert len(list((tmp_path / 'out' / 'dev').glob('*.wav'))) <= 3
 
 
+# ---------------------------------------------------------------- session_id=dev: S02 AND S09
+# (scripts/run.py:45-71 resolves `dev` to both sessions; S09 has five arrays, mapping.py:67, so the
+# channel count changes from 24 to 20 in the middle of a run.  Fixture chime5_dev_sessions.*:
+# the reference's real session code on a two-session corpus, make_golden_session.py)
+@pytest.fixture(scope='module')
+def fixture_dev():
+    return _load_fixture('chime5_dev_sessions')
+
+
+@pytest.fixture(scope='module')
+def corpus_dev(fixture_dev, tmp_path_factory):
+    return _write_corpus(fixture_dev, tmp_path_factory.mktemp('chime5_dev_corpus'))
+
+
+def test_dev_is_two_sessions_behind_one_database(corpus_dev, fixture_dev):
+    from pb_chime5_amd.scripts.run import get_session_ids
+    sessions = get_session_ids('dev')
+    assert sessions == ['S02', 'S09'] == fixture_dev['corpus']['session_id']
+    enh = _enhancer(corpus_dev, fixture_dev)
+    it = enh.get_iterator(sessions)
+    assert len(it) == len(fixture_dev['examples'])
+    keys = ('start', 'end', 'num_samples', 'start_orig', 'end_orig', 'num_samples_orig')
+    for ex, want in zip(it, fixture_dev['examples']):
+        for key in ('example_id', 'speaker_id', 'session_id', 'reference_array') + keys:
+            assert ex[key] == want[key], (ex['example_id'], key)
+    arrays = {s: sorted(next(ex for ex in it if ex['session_id'] == s)['audio_path']['observation'])
+              for s in sessions}
+    assert len(arrays['S02']) == 6 and len(arrays['S09']) == 5 and 'U05' not in arrays['S09']
+    # the activity of each session, both kept (loader threads of a two-session run ask for
+    # either at any time)
+    for session_id in sessions:
+        activity = enh.activity[session_id]
+        want = fixture_dev['activity'][session_id]
+        assert list(activity.keys()) == list(want.keys())
+        for array, tracks in want.items():
+            for spk, intervals in tracks.items():
+                got = [list(map(int, iv)) for iv in activity[array][spk].normalized_intervals]
+                assert got == intervals, (session_id, array, spk)
+    assert enh.activity['S02'] is enh.activity['S02'] and enh.activity['S09'] is enh.activity['S09']
+
+
+@pytest.mark.gpu
+def test_dev_examples_match_reference_at_24_and_20_channels(corpus_dev, fixture_dev):
+    from tests.conftest import rel_err
+    enh = _enhancer(corpus_dev, fixture_dev)
+    it = enh.get_iterator(fixture_dev['corpus']['session_id'])
+    gold = np.load(GOLDEN / 'chime5_dev_sessions.npz')
+    channels = []
+    for idx in fixture_dev['enhanced']:
+        ex = it[idx]
+        x_hat = enh.enhance_example(ex, debug=True)
+        loc = enh.enhance_example_locals
+        assert loc['obs'].shape == tuple(gold[f'obs_shape/{idx}'])
+        channels.append(loc['obs'].shape[0])
+        want = gold[f'x_hat/{idx}']
+        assert x_hat.shape == want.shape
+        assert rel_err(x_hat, want) < 1e-4
+    assert channels == [24, 20]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('loaders,inflight', [(3, 2), (1, 3)])
+def test_dev_session_run_switches_channel_count_mid_run(corpus_dev, fixture_dev, tmp_path,
+                                                        loaders, inflight):
+    """Enhancer.enhance_session(['S02', 'S09']) as `run.py with session_id=dev` calls it: the
+    pipelined driver (loader threads, utterances in flight, staging blocks and device arenas
+    re-sized when the observation goes from 24 to 20 channels and back -- longest-first order
+    interleaves the sessions) writes every WAV byte-identical to the one-at-a-time loop."""
+    sessions = fixture_dev['corpus']['session_id']
+    a, b = tmp_path / 'seq', tmp_path / 'pipe'
+    seq = _enhancer(corpus_dev, fixture_dev)
+    seq.inflight = 1
+    seq.enhance_session(sessions, a)
+    pipe = _enhancer(corpus_dev, fixture_dev)
+    pipe.inflight, pipe.loaders = inflight, loaders
+    pipe.enhance_session(sessions, b)
+    files = sorted(p.relative_to(a) for p in a.rglob('*.wav'))
+    assert len(files) == len(fixture_dev['examples'])
+    assert files == sorted(p.relative_to(b) for p in b.rglob('*.wav'))
+    for rel in files:
+        assert (a / rel).read_bytes() == (b / rel).read_bytes(), rel
+    assert all(rel.parts[0] == 'dev' for rel in files)
+
+
+@pytest.mark.gpu
+def test_dev_session_run_with_two_ranks(corpus_dev, fixture_dev, tmp_path):
+    """The same through the command line with two node-local ranks (longest first across BOTH
+    sessions from the shared counter): every WAV once, byte-equal to one rank."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    common = ['-m', 'pb_chime5_amd.scripts.run', 'with', f'database_path={corpus_dev}',
+              'session_id=dev'] + [f'{k}={v}' for k, v in fixture_dev['enhancer'].items()]
+    env = dict(os.environ, PYTHONPATH=str(REPO))
+    one = subprocess.run([sys.executable] + common + ['-F', str(tmp_path / 'one')], cwd=str(REPO),
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, '-m', 'pb_chime5_amd.parallel', '-n', '2'] + common
+                         + ['-F', str(tmp_path / 'two')], cwd=str(REPO), env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    a, b = tmp_path / 'one' / '1' / 'audio', tmp_path / 'two' / '1' / 'audio'
+    files = sorted(p.relative_to(a) for p in a.rglob('*.wav'))
+    assert len(files) == len(fixture_dev['examples'])
+    assert files == sorted(p.relative_to(b) for p in b.rglob('*.wav'))
+    for rel in files:
+        assert (a / rel).read_bytes() == (b / rel).read_bytes(), rel
+
+
 # ---------------------------------------------------------------- command line
 def test_cli_config_parsing():
     from pb_chime5_amd.scripts import run, kaldi_run, kaldi_run_rttm

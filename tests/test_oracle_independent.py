@@ -23,7 +23,9 @@ import scipy.linalg
 import scipy.signal
 
 import gss_oracle as oracle
-from conftest import rel_err
+from conftest import REPO, rel_err
+
+GOLDEN = REPO / "tests" / "golden"
 
 
 def crandn(rng, *shape):
@@ -381,3 +383,44 @@ def test_gev_by_scipy_generalised_eigh():
         assert abs(abs(c) / (np.linalg.norm(v) * np.linalg.norm(w[f])) - 1) < 1e-10
         ratio = np.real(w[f].conj() @ cov_x[f] @ w[f]) / np.real(w[f].conj() @ cov_n[f] @ w[f])
         assert abs(ratio - vals[-1]) < 1e-9 * vals[-1]
+
+
+def test_extended_precision_guided_em_referee():
+    """tests/ext_precision.guided_em: the guided EM in 80-bit extended precision with its own
+    Jacobi eigensolver -- the referee of the EM fuzz sweeps.  Its eigensolver reproduces
+    A V = V diag(lambda) to extended precision; on well-conditioned scenes it agrees with the
+    oracle and with the brute-force float64 EM to 1e-12; on a scene whose classes are active for
+    fewer frames than there are channels (eigenvalues on the 1e-10 floor: float64 runs scatter
+    around the exact iteration) the oracle's distance from it is covered by the yardstick the
+    sweeps use (oracle - referee, or the oracle's own movement under last-bit input changes)."""
+    import ext_precision as xp
+    rng = np.random.default_rng(77)
+    A = crandn(rng, 9, 9)
+    A = A @ A.conj().T
+    lam, V = xp.eigh(A)
+    assert lam.dtype == np.longdouble
+    resid = np.max(np.abs(A.astype(xp.CLD) @ V - V * lam[None, :]))
+    assert resid < 1e-15 * np.abs(A).max()                       # (float64 LAPACK: ~1e-13)
+    assert np.max(np.abs(V.conj().T @ V - np.eye(9))) < 1e-17
+    assert np.max(np.abs(np.sort(lam.astype(float)) - np.linalg.eigvalsh(A))) < 1e-12
+    for iterations, post in ((1, 1), (5, 1), (4, 0), (3, 3)):
+        obs, act = guided_scene(np.random.default_rng(10 * iterations + post))
+        r = xp.guided_em(obs, act, iterations, post)
+        o = oracle.gss_block_batched(obs.T[..., None], act, iterations=iterations,
+                                     iterations_post=post)[..., 0]
+        b = brute_force_guided_em(obs, act, iterations, post)
+        assert np.max(np.abs(r - o)) < 1e-12 and np.max(np.abs(r - b)) < 1e-12
+    # a scene the 1e-10 floor decides (tools/fuzz_em.py seed 47 case 70: 13 channels, classes
+    # active for 0 - 4 of 52 frames, one M-step + predict): float64 runs scatter by ~5e-7
+    z = np.load(GOLDEN / 'em_floor_decided_case.npz')
+    Of, act = z['obs_f'], z['act']
+    it, post = int(z['iterations']), int(z['iterations_post'])
+    r = xp.guided_em(np.ascontiguousarray(Of[..., 0].T), act, it, post)
+    o = oracle.gss_block_batched(Of, act, iterations=it, iterations_post=post)[..., 0]
+    b = brute_force_guided_em(np.ascontiguousarray(Of[..., 0].T), act, it, post)
+    d_or, d_br = np.max(np.abs(o - r)), np.max(np.abs(b - r))
+    yard = xp.em_yardstick(Of, act, it, post, o, r)
+    print(f'floor-decided scene: oracle - referee {d_or:.1e}, brute force - referee {d_br:.1e}, '
+          f'yardstick {yard:.1e}')
+    assert 1e-8 < d_or <= yard < 1e-5 and d_br < 5 * yard
+    assert np.all(np.abs(r.sum(axis=0) - 1) < 1e-12)

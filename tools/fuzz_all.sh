@@ -29,9 +29,29 @@ run wpe python tools/fuzz_wpe.py 42 400
 run wpe_one_array env GSS_FUZZ_D=4 python tools/fuzz_wpe.py 43 200        # P folded into R's last column tile
 run wpe_24 env GSS_FUZZ_D=24 python tools/fuzz_wpe.py 44 60               # persistent LDS-DMA correlation
 run wpe_20 env GSS_FUZZ_D=20 python tools/fuzz_wpe.py 45 60
+run wpe_12 env GSS_FUZZ_D=12 python tools/fuzz_wpe.py 53 100              # outer microphones: fine tiles, 4 waves share a window
+run wpe_10 env GSS_FUZZ_D=10 python tools/fuzz_wpe.py 54 100
+run wpe_one_array_single_waves env GSS_FUZZ_D=4 GSS_VARIANT=corr_ksplit=1 python tools/fuzz_wpe.py 55 100
 run bf python tools/fuzz_bf.py 46 600
 run em python tools/fuzz_em.py 47 700
 run em_one_array env GSS_FUZZ_D=4 GSS_FUZZ_KMAX=6 GSS_FUZZ_TMAX=1200 python tools/fuzz_em.py 48 500   # em_onchip4_kernel
+run em_blocks env GSS_VARIANT=em_l3_fit_mb=0,em_l3_mb=1 python tools/fuzz_em.py 56 200          # EM over blocks of frequencies, two streams
 for seed in 49 50 51; do run session_$seed python tools/fuzz_session.py $seed 24; done
 run session_gev python tools/fuzz_session.py 52 24 gev_ban
+# machine-written total: every "failures N" / "N failed" / non-zero exit status of the sweeps above
+python3 - "$S" <<'PY' >> $S
+import re, sys
+text = open(sys.argv[1]).read()
+sweeps = len(re.findall(r'^== ', text, re.M))
+failures = sum(int(n) for n in re.findall(r'failures (\d+)', text))
+failed_tests = sum(int(n) for n in re.findall(r'(\d+) failed', text))
+passed_tests = sum(int(n) for n in re.findall(r'(\d+) passed', text))
+cases = sum(int(n) for n in re.findall(r'cases (\d+)', text))
+bad_exit = len([s for s in re.findall(r'exit status (\d+)', text) if s != '0'])
+mism = sum(int(n) for n in re.findall(r'reference-channel mismatches[^0-9]*(\d+)', text))
+total = failures + failed_tests + bad_exit
+print(f'TOTAL: sweeps {sweeps}, stage cases {cases}, pytest cases passed {passed_tests}, failures {failures}, '
+      f'failed tests {failed_tests}, non-zero exits {bad_exit}, reference-channel mismatches {mism} '
+      f'=> {"CLEAN" if total == 0 else "NOT CLEAN: " + str(total)}')
+PY
 cat $S
