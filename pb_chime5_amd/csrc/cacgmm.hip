@@ -1123,10 +1123,15 @@ __device__ __forceinline__ bool class_update_chol(const cplx (&vals)[COV_SLOTS],
 // Eigendecomposition path (exactly the reference): eigenvalues / max, floor, then
 // B^-1 = V diag(1/lambda) V^H and ln det = sum ln lambda.  A, V = m x m complex each and
 // lam = m doubles of LDS owned by this wave, m = D rounded up to even.
+// `basis` (optional, m * m complex that persist between calls for the same class): on entry, if
+// *basis_valid, the eigenvectors of this class's covariance at the previous call -- the sweep
+// starts from B rotated into that basis (nearly diagonal one EM iteration later); on exit the
+// eigenvectors found now.
 __device__ inline void class_update_eigh(const cplx (&vals)[COV_SLOTS], int D, int K,
                                          double eig_floor, cplx *A, int lane,
                                          cplx *__restrict__ Mq_fk,
-                                         double *__restrict__ logdet_fk, const TriSlots &ts) {
+                                         double *__restrict__ logdet_fk, const TriSlots &ts,
+                                         cplx *basis = nullptr, int *basis_valid = nullptr) {
     const int m = D + (D & 1);
     cplx *V = A + m * m;
     double *lam = reinterpret_cast<double *>(V + m * m);
@@ -1134,7 +1139,42 @@ __device__ inline void class_update_eigh(const cplx (&vals)[COV_SLOTS], int D, i
     wave_sync();
     store_covariance(vals, D, 0.0, true, A, m, lane, ts);
     wave_sync();
-    jacobi_eigh_wave(A, V, m, lane, 20);
+    const bool warm = basis != nullptr && *basis_valid != 0;
+    if (warm) {
+        // A <- W^H B W, upper triangle computed and mirrored (exactly Hermitian), V <- W
+        cplx rot[4];                              // m * m <= 256 entries over 64 lanes
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int idx = lane + 64 * s, i = idx / m, j = idx - i * m;
+            rot[s] = c_make(0.0, 0.0);
+            if (idx < m * m && i <= j) {
+                for (int a = 0; a < m; ++a) {
+                    cplx t = c_make(0.0, 0.0);
+                    for (int b = 0; b < m; ++b) c_fma(t, A[a * m + b], basis[b * m + j]);
+                    c_cfma(rot[s], basis[a * m + i], t);
+                }
+                if (i == j) rot[s].y = 0.0;
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int idx = lane + 64 * s, i = idx / m, j = idx - i * m;
+            if (idx < m * m) {
+                V[idx] = basis[idx];
+                if (i <= j) {
+                    A[i * m + j] = rot[s];
+                    A[j * m + i] = c_conj(rot[s]);
+                }
+            }
+        }
+        wave_sync();
+    }
+    jacobi_eigh_wave(A, V, m, lane, 20, warm);
+    if (basis != nullptr) {
+        for (int idx = lane; idx < m * m; idx += 64) basis[idx] = V[idx];
+        if (lane == 0) *basis_valid = 1;
+    }
     double lmax = -INFINITY;
     for (int i = lane; i < D; i += 64) lmax = fmax(lmax, A[i * m + i].x);
     lmax = wave_max(lmax);
@@ -1289,6 +1329,7 @@ struct OnchipArgs {
     const uint8_t *act;     // (K, act_stride)
     int64_t act_stride, T;
     int F, iterations, iterations_post, force_eigh;
+    int cold_eigh;          // GSS_VARIANT em4_cold_eigh: every eigendecomposition from the identity
     double eig_floor;
     double *gamma;          // (F, K, T)
 };
@@ -1412,6 +1453,12 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
     __shared__ __attribute__((aligned(16))) double mR[NP][2 * KP];
     __shared__ __attribute__((aligned(16))) cplx MqS[NE * K];      // (flagged classes: em_eigh's layout)
     __shared__ int flagS;
+    // flagged classes: the eigenvectors of the previous iteration's covariance, where the next
+    // Jacobi sweep starts (a class that fails the certificate tends to fail it in EVERY
+    // iteration -- a speaker with a handful of active frames --, and its workgroup was the one
+    // the whole launch waited for: 7 - 8 cold sweeps per iteration, 2 - 3 from here)
+    __shared__ __attribute__((aligned(16))) cplx basisS[K][16];
+    __shared__ int basis_validS[K];
     // scratch of the flagged-class path (one wave per class: Cholesky sweep / Jacobi): the
     // rows above are idle during the model update
     constexpr int CH_LD = 9;
@@ -1427,6 +1474,7 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
     const int nsub = (int)((T + OC_FRAMES - 1) / OC_FRAMES);
     const int mi = lane >> 2, msl = lane & 3;         // phase M: entry number, frame slice
     const TriSlots ts = tri_slots(D, lane);
+    if (tid < K) basis_validS[tid] = 0;         // (published by the barriers of the first update)
 
 #ifdef GSS_EM4_TRACE
     long long em4_acc[6] = {0, 0, 0, 0, 0, 0};
@@ -1678,7 +1726,8 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
                     }
                 }
                 cplx *A = reinterpret_cast<cplx *>(&ldsS[wave][0][0]);
-                class_update_eigh(vals, D, K, a.eig_floor, A, lane, MqS + k, logdetS + k, ts);
+                class_update_eigh(vals, D, K, a.eig_floor, A, lane, MqS + k, logdetS + k, ts,
+                                  a.cold_eigh ? nullptr : basisS[k], basis_validS + k);
                 wave_sync();
                 if (lane < NE) {
                     const cplx v = MqS[lane * K + k];
@@ -2212,6 +2261,7 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
         o.iterations = iterations;
         o.iterations_post = iterations_post;
         o.force_eigh = force_eigh;
+        o.cold_eigh = gss_variant_set("em4_cold_eigh");
         o.eig_floor = 1e-10;
         o.gamma = gamma;
         switch (K) {

@@ -20,12 +20,17 @@
 // the eigenvalues.  V: m x m, on exit column j is the eigenvector of A[j][j].
 // If m was padded from an odd size the pad row/column must be zero on entry; it
 // then stays decoupled.  Returns the number of sweeps.
-__device__ inline int jacobi_eigh_wave(cplx *A, cplx *V, int m, int lane, int max_sweeps) {
+// WARM: V holds a unitary W on entry and A = W^H B W (Hermitian): the rotations go on from
+// there and V leaves as the eigenvectors of B -- when W is the eigenbasis of a nearby matrix
+// (the same class one EM iteration ago) A is nearly diagonal and two or three sweeps do.
+__device__ inline int jacobi_eigh_wave(cplx *A, cplx *V, int m, int lane, int max_sweeps,
+                                       bool warm = false) {
     const int half = m >> 1;
     const int pr = lane & 15, grp = lane >> 4;
     const bool active = pr < half;
-    for (int i = grp; i < m; i += 4)
-        for (int j = pr; j < m; j += 16) V[i * m + j] = c_make(i == j ? 1.0 : 0.0, 0.0);
+    if (!warm)
+        for (int i = grp; i < m; i += 4)
+            for (int j = pr; j < m; j += 16) V[i * m + j] = c_make(i == j ? 1.0 : 0.0, 0.0);
     wave_sync();
     int sweep = 0;
     bool last = false;

@@ -43,10 +43,20 @@ CORPUS = dict(session_id='S02', seconds=9.0, seed=11, utts_per_speaker=2, num_re
 ENHANCER = dict(context_samples=16000, multiarray='outer_array_mics', wpe=True, wpe_tabs=4,
                 wpe_iterations=2, bss_iterations=5)
 EXAMPLES = (0, 5)
-DEV_CORPUS = dict(session_id=['S02', 'S09'], seconds=7.0, seed=23, utts_per_speaker=1, num_redacted=1)
+# dense overlap and diffuse noise: with all 24 microphones the noise PSD matrix needs more than 24
+# frames' worth of distortion-mask mass inside the core of an utterance, or the reference's own
+# beamformer output is rounding noise (cond(Phi_N) 1e16 on a sparser corpus; here <= 6e5)
+DEV_CORPUS = dict(session_id=['S02', 'S09'], seconds=6.0, seed=23, utts_per_speaker=4, num_redacted=1,
+                  noise=0.1)
 DEV_ENHANCER = dict(context_samples=12000, multiarray=True, wpe=True, wpe_tabs=2,
                     wpe_iterations=2, bss_iterations=4)
-DEV_EXAMPLES = (1, 6)          # one of S02 (24 channels), one of S09 (20 channels)
+# one of S02 (24 channels), one of S09 (20 channels), both well posed in the reference's own
+# float64 arithmetic.  (Not all 32 are: in examples 0, 4, 9, 10, 21, 22, 26, 29 the WPE normal
+# equations of the lowest bins are conditioned so badly that two float64 solves differ by
+# 1e-6 ... 5e-5 after WPE already, and in example 18 one bin's distortion mask sums to 8 frames
+# on 20 channels -- cond(Phi_N) = 2e18, the reference's output there is 1e10 and its reference
+# channel a coin toss.  Measured with tools/fuzz_case.py-style stage comparisons in round 6.)
+DEV_EXAMPLES = (2, 28)
 
 
 # ---------------------------------------------------------------- stand-ins

@@ -381,6 +381,11 @@ def test_cacgmm_one_array_kernel_equals_three_launch_path(gpu_ctx, monkeypatch, 
     three = ops.cacgmm_posteriors(Y, act, 8, post, ctx=gpu_ctx)
     monkeypatch.setenv('GSS_VARIANT', 'force_eigh')
     eigh = ops.cacgmm_posteriors(Y, act, 8, post, ctx=gpu_ctx)
+    # ... whose Jacobi sweeps start from the class's eigenvectors of the previous iteration
+    # (default) or from the identity every time
+    monkeypatch.setenv('GSS_VARIANT', 'force_eigh,em4_cold_eigh')
+    cold = ops.cacgmm_posteriors(Y, act, 8, post, ctx=gpu_ctx)
+    assert np.max(np.abs(cold - eigh)) < 1e-9
     monkeypatch.delenv('GSS_VARIANT')
     want = oracle.gss_block(Y, act, 8, post)
     print(f'K={K} post={post}: one launch vs three {np.max(np.abs(one - three)):.1e}, vs eigh path '
