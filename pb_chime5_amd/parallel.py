@@ -172,6 +172,7 @@ def init(backend=None):
     bind_to_gpu_numa()       # (a single rank also wants its threads on its GPU's socket)
     if world_size() == 1:
         return None
+    _warn_if_ranks_share_a_package()
     if backend is None and not os.environ.get('GSS_DIST_BACKEND') and _local_group() is not None:
         return None                       # node-local ranks of launch_local: no process group
     import torch
@@ -187,6 +188,25 @@ def init(backend=None):
             torch.cuda.set_device(device_index())
         dist.init_process_group(backend=backend)
     return dist
+
+
+def _warn_if_ranks_share_a_package():
+    """Rank 0 of a node says so once when its ranks outnumber the physical GPUs although every
+    rank has a logical device of its own (a CPX / NPS-partitioned node: 64 logical devices on 8
+    packages): the throughput of such a run is not that of LOCAL_WORLD_SIZE GPUs."""
+    if local_rank() != 0:
+        return
+    try:
+        from pb_chime5_amd import _capi
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world_size()))
+        bus_ids = [_capi.device_pci_bus_id(i) for i in range(_capi.device_count())]
+        packages = len({_capi.pci_package(b) for b in bus_ids})
+        if packages and packages < local_world <= len(bus_ids):
+            print(f'pb_chime5_amd.parallel: {local_world} ranks on {packages} physical GPUs '
+                  f'({len(bus_ids)} logical devices: a partitioned node) -- ranks share packages',
+                  file=sys.stderr)
+    except Exception:            # noqa: BLE001 -- a diagnostic, never an error
+        pass
 
 
 def _local_group():
