@@ -1324,7 +1324,7 @@ extern "C" int gss_debug_em4_phase(long long *host, int entries) {
 #endif
 
 struct OnchipArgs {
-    cplx *Mq;               // (F, NE, K) model scratch (written and re-read by the same workgroup)
+    cplx *basis;            // (F, K, 16) eigenvectors of flagged classes, one EM iteration back
     const cplx *Yn;         // (F, 4, T) unit-normalised observation
     const uint8_t *act;     // (K, act_stride)
     int64_t act_stride, T;
@@ -1457,13 +1457,16 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
     // Jacobi sweep starts (a class that fails the certificate tends to fail it in EVERY
     // iteration -- a speaker with a handful of active frames --, and its workgroup was the one
     // the whole launch waited for: 7 - 8 cold sweeps per iteration, 2 - 3 from here)
-    __shared__ __attribute__((aligned(16))) cplx basisS[K][16];
+    // They live in global memory (a.basis: L2 resident, touched by flagged classes only) and pass
+    // through the wave's idle rows: 1.5 KB more of LDS per workgroup would cost K = 6 its third
+    // workgroup per CU -- and with 513 frequencies on 256 CUs the third is the one that matters.
     __shared__ int basis_validS[K];
     // scratch of the flagged-class path (one wave per class: Cholesky sweep / Jacobi): the
     // rows above are idle during the model update
     constexpr int CH_LD = 9;
     constexpr int SCRATCH = (2 * 4 * 4 + D * CH_LD) * sizeof(cplx) + 64;
-    static_assert(SCRATCH <= sizeof(double) * (K + NP) * OC_LD, "scratch aliases a wave's rows");
+    static_assert(SCRATCH <= 80 * sizeof(cplx) && 96 * sizeof(cplx) <= sizeof(double) * (K + NP) * OC_LD,
+                  "scratch and the warm-start basis alias a wave's rows");
     const int64_t T = a.T;
     const int f = (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1726,8 +1729,13 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
                     }
                 }
                 cplx *A = reinterpret_cast<cplx *>(&ldsS[wave][0][0]);
+                cplx *basis = A + 80;                  // (behind A, V, lambda and the sweep's ring)
+                cplx *basis_g = a.basis + ((int64_t)f * K + k) * 16;
+                if (!a.cold_eigh && basis_validS[k] && lane < 16) basis[lane] = basis_g[lane];
+                wave_sync();
                 class_update_eigh(vals, D, K, a.eig_floor, A, lane, MqS + k, logdetS + k, ts,
-                                  a.cold_eigh ? nullptr : basisS[k], basis_validS + k);
+                                  a.cold_eigh ? nullptr : basis, basis_validS + k);
+                if (!a.cold_eigh && lane < 16) basis_g[lane] = basis[lane];
                 wave_sync();
                 if (lane < NE) {
                     const cplx v = MqS[lane * K + k];
@@ -2021,9 +2029,10 @@ int mstep_plan(gss_ctx *ctx, int F, int64_t T, int D, int K, MsegPlan *plan) {
 //   em_streams    blocks in flight (1 | 2)                                      (default 2)
 // MEASURED in round 6 and NOT the default (EXPERIMENTS.md, round 6 item 1): at config 5 the
 // resident blocks are slower per frequency than the launches that stream from HBM (E-step
-// 0.51 vs 0.43 us per frequency, M-step likewise; 6 blocks 48.3 ms, 2 blocks 42.0 ms, one
-// block 41.7 ms per utterance) -- the launches are bound by VALU issue and by their ramp and
-// tail, not by where the bytes come from, and short launches have more ramp and tail.
+// 0.53 vs 0.43 us per frequency, M-step 0.71 vs 0.59; 6 blocks 48.3 ms, 2 blocks 42.0 ms, one
+// block 41.7 ms per utterance).  A read stream gets the same 6.3 - 6.7 TB/s from the Infinity
+// Cache as from HBM (tools/micro/hbm_stream_bench.hip) and the E-step already runs at 0.85 of
+// a traffic-only kernel with its access pattern; short launches only add ramp and tail.
 // Per-frequency arithmetic is unchanged except for the grouping of the M-step's partial sums
 // (the chunking / static partition depends on the number of frequencies of a launch).
 struct EmBlockPlan {
@@ -2097,7 +2106,7 @@ size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K) {
     b += align_up(sizeof(int) * 2 * NE);                         // tri_tab
     b += align_up(sizeof(cplx) * (size_t)F * D * T);             // Yn (register-form E-step)
     b += align_up(sizeof(double) * (size_t)F * st.reg_nch * K);  // Sg of the register-form E-step
-    b += 2 * align_up(16 * (2 + 16 * (K * 17) + 16 * (K + 1) + 2 * K + 8 + 16 * NE * K));   // em_onchip coop
+    b += align_up(sizeof(cplx) * (size_t)F * K * 16);            // em_onchip4: warm-start eigenvectors (D = 4)
     return b + 4096;
 }
 
@@ -2252,7 +2261,8 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
         GSS_TRY(make_block(0, F, ctx->stream, &b));
         GSS_TRY(prepare(b));
         OnchipArgs o{};
-        o.Mq = Mq;
+        o.basis = arena_alloc_t<cplx>(ctx, (size_t)F * K * 16);
+        GSS_REQUIRE(ctx, o.basis, GSS_ERR_NOMEM, "cacgmm workspace");
         o.Yn = Yn;
         o.act = act;
         o.act_stride = act_stride;

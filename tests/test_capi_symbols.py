@@ -145,3 +145,49 @@ def test_step_flops_and_traffic_provenance(tmp_path):
     assert roofline.kernel_sources('psd')[0] == 'mvdr.hip'
     hashes = roofline.source_hashes()
     assert {'wpe.hip', 'cacgmm.hip', 'mvdr.hip', 'stft.hip', 'gss_api.hip', 'gss_internal.h'} <= set(hashes)
+
+
+def test_occupancy_budgets_of_the_resident_kernels(tmp_path):
+    """Kernels whose launch shape depends on how many workgroups a CU holds, checked in the code
+    objects of the in-tree build (llvm-objdump --offloading + llvm-readelf --notes):
+    * em_onchip4_kernel<K> (one array: 513 workgroups on 256 CUs) must fit THREE workgroups per
+      CU for every K -- LDS <= 160 KB / 3 and <= 168 VGPRs --, or the 513th workgroup runs alone
+      in a second round (a 1.5 KB array added in round 6 cost K = 6 exactly that until it moved
+      to global memory);
+    * the single-wave / frame-splitting correlation kernels of one array fit four waves per SIMD
+      (<= 128 VGPRs): at 138 the last 6 of 3078 waves ran in a second round."""
+    import re
+    import shutil
+    import subprocess
+    from pathlib import Path
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    lib = REPO / 'pb_chime5_amd' / 'lib'
+    if not (llvm / 'llvm-readelf').exists() or not (lib / 'cacgmm.o').exists():
+        pytest.skip('llvm-readelf or the per-unit objects of an in-tree build are missing')
+    from pb_chime5_amd import build
+    build.build(verbose=False)                      # objects of the CURRENT sources
+
+    def kernels(unit):
+        obj = tmp_path / f'{unit}.o'
+        shutil.copy(lib / f'{unit}.o', obj)
+        subprocess.run([str(llvm / 'llvm-objdump'), '--offloading', str(obj)], check=True,
+                       capture_output=True, cwd=tmp_path)
+        co = next(tmp_path.glob(f'{unit}.o.*gfx950*'))
+        notes = subprocess.run([str(llvm / 'llvm-readelf'), '--notes', str(co)], check=True,
+                               capture_output=True, text=True).stdout
+        out = {}
+        for block in notes.split('  - .agpr_count:')[1:]:
+            name = re.search(r'\.name:\s+(\S+)', block).group(1)
+            out[name] = {k: int(re.search(rf'\.{k}:\s+(\d+)', block).group(1))
+                         for k in ('group_segment_fixed_size', 'vgpr_count', 'private_segment_fixed_size')}
+        return out
+    em = {n: v for n, v in kernels('cacgmm').items() if 'em_onchip4_kernel' in n}
+    assert len(em) == 5, sorted(em)                 # K = 2 ... 6
+    for name, meta in em.items():
+        assert meta['group_segment_fixed_size'] <= 160 * 1024 // 3, (name, meta)
+        assert meta['vgpr_count'] <= 168, (name, meta)
+    corr = {n: v for n, v in kernels('wpe').items()
+            if 'wpe_corr_ksplit_kernelILi4ELi5E' in n or 'wpe_corr_kernelILi1ELi1ELi5E' in n}
+    assert len(corr) == 2, sorted(corr)
+    for name, meta in corr.items():
+        assert meta['vgpr_count'] <= 128 and meta['private_segment_fixed_size'] == 0, (name, meta)

@@ -48,7 +48,8 @@ failed_tests = sum(int(n) for n in re.findall(r'(\d+) failed', text))
 passed_tests = sum(int(n) for n in re.findall(r'(\d+) passed', text))
 cases = sum(int(n) for n in re.findall(r'cases (\d+)', text))
 bad_exit = len([s for s in re.findall(r'exit status (\d+)', text) if s != '0'])
-mism = sum(int(n) for n in re.findall(r'reference-channel mismatches[^0-9]*(\d+)', text))
+mism = sum(len([x for x in body.split(',') if x.strip()])
+           for body in re.findall(r'reference-channel mismatches: \[(.*?)\]', text))
 total = failures + failed_tests + bad_exit
 print(f'TOTAL: sweeps {sweeps}, stage cases {cases}, pytest cases passed {passed_tests}, failures {failures}, '
       f'failed tests {failed_tests}, non-zero exits {bad_exit}, reference-channel mismatches {mism} '
