@@ -46,7 +46,7 @@ namespace {
 const char *const kVariantKeys[] = {
     // wpe.hip
     "corr_ts", "corr_nw", "corr_blocked", "corr_p_tiles", "chol_diag_unfolded", "apply_ph",
-    "apply_generic", "prof_detail", "corr_stg8", "corr_ksplit",
+    "apply_generic", "prof_detail", "corr_stg8", "corr_ksplit", "apply_gglobal",
     // cacgmm.hip
     "em_wgs", "estep_wpb", "estep_lds", "mstep_prefetch_d", "mstep_tiled", "mstep_plan_min_d",
     "mstep_chunked", "mstep_slots", "force_eigh", "em_unfused", "em_l3_mb", "em_l3_fit_mb",

@@ -73,14 +73,25 @@ __device__ __forceinline__ cplx c_div(cplx a, cplx b) {
     return c_make((a.x * r + a.y) / den, (a.y * r - a.x) / den);
 }
 
-// Per frequency (one wave): Phi_X, Phi_N from the partial sums; Psi = solve(Phi_N,
-// Phi_X) by LU with partial pivoting, pseudo-inverse (lstsq) fallback on an exactly
-// singular Phi_N; W = Psi / max(Re tr Psi, eps); per-reference-channel SNR terms.
-__global__ __launch_bounds__(64) void mvdr_solve_kernel(
+// Per frequency (one workgroup of MVDR_NT threads): Phi_X, Phi_N from the partial sums;
+// Psi = solve(Phi_N, Phi_X) by LU with partial pivoting, pseudo-inverse (lstsq) fallback on an
+// exactly singular Phi_N; W = Psi / max(Re tr Psi, eps); per-reference-channel SNR terms.
+// Every element of every step is computed by exactly the expressions a single wave used until
+// round 5 (the rank-1 update of an LU step, the products of the SNR terms are element-wise), so
+// the result does not depend on the thread count: four waves take the 23 x 47 element update of
+// the first step in 5 trips instead of 17 -- the kernel was one wave's latency chain per
+// frequency (120 us for ~10 000 instructions), not work.  Pivot search, back substitution (one
+// right-hand side per lane) and the Jacobi fallback stay with wave 0.
+#ifndef GSS_MVDR_NT
+#define GSS_MVDR_NT 256        // (tools/build_variant.sh NAME -DGSS_MVDR_NT=64: the same bits from one wave)
+#endif
+constexpr int MVDR_NT = GSS_MVDR_NT;
+__global__ __launch_bounds__(MVDR_NT) void mvdr_solve_kernel(
     const cplx *__restrict__ part, const double *__restrict__ msum, int nch, int D, double eps,
     cplx *__restrict__ Phi /* (F,2,D,D) */, cplx *__restrict__ W /* (F,D,D) */,
     cplx *__restrict__ snr /* (F,D,2) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = MVDR_NT;
     const int m = D + (D & 1);
     const int NE = tri_count(D);
     const int W2 = 2 * D;
@@ -92,13 +103,15 @@ __global__ __launch_bounds__(64) void mvdr_solve_kernel(
     int *flags = reinterpret_cast<int *>(JV + m * m);
     int &s_piv = flags[0];
     int &s_singular = flags[1];
-    const int f = blockIdx.x, lane = threadIdx.x;
+    double &s_dentr = *reinterpret_cast<double *>(flags + 2);
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const bool wave0 = tid < 64;                   // (D <= 32: one wave holds a column)
 
     const double sx = msum[f * 2], sn = msum[f * 2 + 1];
     const double dx = fmax(sx, 1e-10), dn = fmax(sn, 1e-10);
     cplx *PhiX = Phi + (int64_t)f * 2 * D * D;
     cplx *PhiN = PhiX + D * D;
-    for (int e = lane; e < NE; e += 64) {
+    for (int e = tid; e < NE; e += NT) {
         // invert the packed index
         int d1 = 0, rem = e;
         while (rem >= D - d1) {
@@ -127,36 +140,38 @@ __global__ __launch_bounds__(64) void mvdr_solve_kernel(
         aug[d1 * W2 + D + d2] = vx;
         aug[d2 * W2 + D + d1] = c_conj(vx);
     }
-    if (lane == 0) s_singular = 0;
+    if (tid == 0) s_singular = 0;
     __syncthreads();
 
     // ---- LU with partial pivoting (pivot by |re| + |im| like LAPACK izamax)
     for (int j = 0; j < D; ++j) {
-        double best = -1.0;
-        int bi = j;
-        if (lane >= j && lane < D) {
-            const cplx v = aug[lane * W2 + j];
-            best = fabs(v.x) + fabs(v.y);
-            bi = lane;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ob = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ob > best || (ob == best && oi < bi)) {
-                best = ob;
-                bi = oi;
+        if (wave0) {
+            double best = -1.0;
+            int bi = j;
+            if (lane >= j && lane < D) {
+                const cplx v = aug[lane * W2 + j];
+                best = fabs(v.x) + fabs(v.y);
+                bi = lane;
             }
-        }
-        if (lane == 0) {
-            s_piv = bi;
-            if (!(best > 0.0)) s_singular = 1;   // zero or NaN pivot
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ob > best || (ob == best && oi < bi)) {
+                    best = ob;
+                    bi = oi;
+                }
+            }
+            if (lane == 0) {
+                s_piv = bi;
+                if (!(best > 0.0)) s_singular = 1;   // zero or NaN pivot
+            }
         }
         __syncthreads();
         if (s_singular) break;
         const int p = s_piv;
         if (p != j) {
-            for (int col = lane; col < W2; col += 64) {
+            for (int col = tid; col < W2; col += NT) {
                 const cplx t = aug[j * W2 + col];
                 aug[j * W2 + col] = aug[p * W2 + col];
                 aug[p * W2 + col] = t;
@@ -166,12 +181,12 @@ __global__ __launch_bounds__(64) void mvdr_solve_kernel(
         const cplx piv = aug[j * W2 + j];
         const int rows = D - j - 1, cols = W2 - j - 1;
         // multipliers first (column j), then the rank-1 update
-        for (int i = lane; i < rows; i += 64) {
+        for (int i = tid; i < rows; i += NT) {
             const int r = j + 1 + i;
             aug[r * W2 + j] = c_div(aug[r * W2 + j], piv);
         }
         __syncthreads();
-        for (int it = lane; it < rows * cols; it += 64) {
+        for (int it = tid; it < rows * cols; it += NT) {
             const int i = it / cols, cidx = it - i * cols;
             const int r = j + 1 + i, col = j + 1 + cidx;
             const cplx l = aug[r * W2 + j], u = aug[j * W2 + col];
@@ -185,8 +200,8 @@ __global__ __launch_bounds__(64) void mvdr_solve_kernel(
     const bool singular = s_singular != 0;
     if (!singular) {
         // back substitution U Psi = Z, one right-hand side per lane
-        if (lane < D) {
-            const int col = D + lane;
+        if (tid < D) {
+            const int col = D + tid;
             for (int j = D - 1; j >= 0; --j) {
                 cplx v = aug[j * W2 + col];
                 for (int k = j + 1; k < D; ++k) {
@@ -201,19 +216,23 @@ __global__ __launch_bounds__(64) void mvdr_solve_kernel(
     } else {
         // np.linalg.lstsq(Phi_N, Phi_X): minimum-norm solution via the Hermitian
         // eigendecomposition; singular values below eps * D * max are dropped.
-        for (int idx = lane; idx < m * m; idx += 64) {
+        for (int idx = tid; idx < m * m; idx += NT) {
             const int i = idx / m, jx = idx - i * m;
             JA[idx] = (i < D && jx < D) ? PhiN[i * D + jx] : c_make(0.0, 0.0);
         }
         __syncthreads();
-        jacobi_eigh_wave(JA, JV, m, lane, 20);
-        double lmax = 0.0;
-        for (int i = lane; i < D; i += 64) lmax = fmax(lmax, fabs(JA[i * m + i].x));
-        lmax = wave_max(lmax);
-        const double cut = 2.220446049250313e-16 * (double)D * lmax;
+        if (wave0) {
+            jacobi_eigh_wave(JA, JV, m, lane, 20);
+            double lmax = 0.0;
+            for (int i = lane; i < D; i += 64) lmax = fmax(lmax, fabs(JA[i * m + i].x));
+            lmax = wave_max(lmax);
+            if (lane == 0) s_dentr = 2.220446049250313e-16 * (double)D * lmax;
+        }
+        __syncthreads();
+        const double cut = s_dentr;
         // Psi = V diag(1/l) V^H Phi_X   (two small products through `aug`)
         // step 1: tmp = V^H Phi_X  -> aug[:, 0:D]
-        for (int it = lane; it < D * D; it += 64) {
+        for (int it = tid; it < D * D; it += NT) {
             const int j = it / D, col = it - j * D;
             cplx v = c_make(0.0, 0.0);
             for (int i = 0; i < D; ++i) c_cfma(v, JV[i * m + j], PhiX[i * D + col]);
@@ -222,7 +241,7 @@ __global__ __launch_bounds__(64) void mvdr_solve_kernel(
             aug[j * W2 + col] = c_scale(v, il);
         }
         __syncthreads();
-        for (int it = lane; it < D * D; it += 64) {
+        for (int it = tid; it < D * D; it += NT) {
             const int i = it / D, col = it - i * D;
             cplx v = c_make(0.0, 0.0);
             for (int j = 0; j < D; ++j) c_fma(v, JV[i * m + j], aug[j * W2 + col]);
@@ -231,12 +250,18 @@ __global__ __launch_bounds__(64) void mvdr_solve_kernel(
         __syncthreads();
     }
     // Psi = aug[:, D:2D].  W = Psi / max(Re tr Psi, eps)
-    double tr = 0.0;
-    for (int i = lane; i < D; i += 64) tr += aug[i * W2 + D + i].x;
-    tr = wave_sum(tr);
-    const double dentr = fmax(tr, eps);
+    if (wave0) {
+        double tr = 0.0;
+        for (int i = lane; i < D; i += 64) tr += aug[i * W2 + D + i].x;
+        tr = wave_sum(tr);
+        if (lane == 0) s_dentr = fmax(tr, eps);
+    }
+    __syncthreads();
+    const double dentr = s_dentr;
     cplx *Wf = W + (int64_t)f * D * D;
-    for (int it = lane; it < D * D; it += 64) {
+    // (every thread reads its elements of Psi before anyone overwrites the left half: the two
+    // halves are disjoint, W goes to the left one)
+    for (int it = tid; it < D * D; it += NT) {
         const int i = it / D, col = it - i * D;
         const cplx v = aug[i * W2 + D + col];
         const cplx wv = c_make(v.x / dentr, v.y / dentr);
@@ -246,9 +271,11 @@ __global__ __launch_bounds__(64) void mvdr_solve_kernel(
     __syncthreads();
     // SNR terms per reference channel r: w_r^H Phi_X w_r and w_r^H Phi_N w_r.  The products
     // T_X = Phi_X W (-> right half of aug) and T_N = Phi_N W (-> JA) are spread over the whole
-    // wave; the sums over e and then over d run in the same order as one lane per r would
+    // workgroup; the sums over e and then over d run in the same order as one lane per r would
     // take them.
-    for (int it = lane; it < D * D; it += 64) {
+    // (reads: W in the left half of aug, Phi_X / Phi_N in global memory; writes: the right half
+    // and JA -- disjoint, no barrier inside)
+    for (int it = tid; it < D * D; it += NT) {
         const int d = it / D, r = it - d * D;
         cplx tx = c_make(0.0, 0.0), tn = c_make(0.0, 0.0);
         for (int e = 0; e < D; ++e) {
@@ -260,8 +287,8 @@ __global__ __launch_bounds__(64) void mvdr_solve_kernel(
         JA[d * m + r] = tn;
     }
     __syncthreads();
-    if (lane < D) {
-        const int r = lane;
+    if (tid < D) {
+        const int r = tid;
         cplx num = c_make(0.0, 0.0), den = c_make(0.0, 0.0);
         for (int d = 0; d < D; ++d) {
             const cplx wd = aug[d * W2 + r];
@@ -608,12 +635,12 @@ int mvdr_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double 
             GSS_PROF(ctx, "mvdr_solve");
             const int m = D + (D & 1);
             const size_t lds = (sizeof(cplx) * ((size_t)D * 2 * D + 2 * (size_t)m * m) +
-                                16 + 15) / 16 * 16;
+                                32 + 15) / 16 * 16;
             if (lds > 64 * 1024)
                 GSS_HIP_CHECK(ctx, hipFuncSetAttribute(
                                        reinterpret_cast<const void *>(mvdr_solve_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(mvdr_solve_kernel, dim3(F), dim3(64), lds, ctx->stream, part, msum, nch,
+            hipLaunchKernelGGL(mvdr_solve_kernel, dim3(F), dim3(MVDR_NT), lds, ctx->stream, part, msum, nch,
                                D, 1e-10, Phi, W, snr);
             GSS_LAUNCH_CHECK(ctx, "mvdr_solve_kernel");
         }

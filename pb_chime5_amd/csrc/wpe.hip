@@ -1509,17 +1509,22 @@ __global__ __launch_bounds__(64 * NWV) void wpe_apply_kernel(const cplx *__restr
 // measured slower in round 1), the window as before; frame f of the window lives at
 // f DP + f / PH so that the rows of a fragment (frames PH i) are an odd number of elements
 // apart.  grid (ceil(T / (64 PH)), F), block 256: one 16-row tile (16 PH frames) per wave.
-template <int PH, int NT>
+// GLDS = false (20 / 24 channels, round 6): G stays in global memory (92 KB per frequency, L2
+// resident and shared by the 8 workgroups of a frequency) -- with G in LDS the packed form owns
+// a CU alone at these channel counts (1.82 vs 1.35 ms in round 4); the operands are requested
+// two k-steps (18 MFMAs) ahead.  Opt-in (GSS_VARIANT apply_gglobal): measured slower than the
+// unpacked kernel, see wpe_run.
+template <int PH, int NT, bool GLDS = true>
 __global__ __launch_bounds__(256) void wpe_apply_packed_kernel(const cplx *__restrict__ Y,
                                                                const cplx *__restrict__ G, int F,
                                                                int64_t T, int D, int n, int c,
                                                                cplx *__restrict__ X) {
     constexpr int WG_ROWS = 64, WG_FRAMES = PH * WG_ROWS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int DP = D | 1, DG = D | 1;
+    const int DP = D | 1, DG = GLDS ? (D | 1) : D;
     const int frames_lds = WG_FRAMES + c + 2;
     cplx *S = reinterpret_cast<cplx *>(smem);                   // frames_lds * DP + frames_lds / PH + 1
-    cplx *Gs = S + (frames_lds * DP + frames_lds / PH + 1);     // (n + 1) * DG, last row zeros
+    cplx *Gl = S + (frames_lds * DP + frames_lds / PH + 1);     // (n + 1) * DG, last row zeros
     int f, chunk;
     if (!xcd_group_map((int)((T + WG_FRAMES - 1) / WG_FRAMES), F, f, chunk)) return;
     const int64_t t0 = (int64_t)chunk * WG_FRAMES;
@@ -1546,7 +1551,8 @@ __global__ __launch_bounds__(256) void wpe_apply_packed_kernel(const cplx *__res
             }
         }
     }
-    {   // G -> LDS
+    if (GLDS) {   // G -> LDS
+        cplx *Gs = Gl;
         const int total = n * D;
         for (int base = 0; base < total; base += NTHR * PRE) {
             cplx v[PRE];
@@ -1565,6 +1571,10 @@ __global__ __launch_bounds__(256) void wpe_apply_packed_kernel(const cplx *__res
         for (int d = threadIdx.x; d < DG; d += NTHR) Gs[n * DG + d] = c_make(0.0, 0.0);
     }
     __syncthreads();
+    // where the B operand comes from: the LDS copy (row n = zeros) or G itself (columns past
+    // PH D then read row 0: their products are computed and never stored)
+    const cplx *Gs = GLDS ? Gl : Gf;
+    const int gzero = GLDS ? n * DG : 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
     const int row = 16 * wave + li;                         // A row of this lane: frames PH row + p
@@ -1636,12 +1646,65 @@ __global__ __launch_bounds__(256) void wpe_apply_packed_kernel(const cplx *__res
         advance();
     };
     for (int ks = 0; ks < ks_head; ++ks) checked_step();
+    if (!GLDS && ks_tail > ks_head) {
+        // body with G from global memory (L2): operands TWO k-steps ahead in a ring of three
+        // register sets (one k-step = 9 MFMAs does not cover an L2 round trip under load:
+        // one-ahead measured 1.41 ms per utterance against 1.26 for the unpacked kernel).  The
+        // first (body length mod 3) k-steps go through the checked form.
+        int ks = ks_head;
+        for (int r = (ks_tail - ks_head) % 3; r > 0; --r, ++ks) checked_step();
+        int ga[NT], ginc[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            ga[b] = colv[b] ? (k - colp[b] * D) * DG + cold[b] : gzero;
+            ginc[b] = colv[b] ? 4 * DG : 0;
+        }
+        auto load = [&](cplx &u, cplx (&g)[NT]) {      // operands of the load cursor's k-step
+            u = S[u_addr()];
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                g[b] = Gs[ga[b]];
+                ga[b] += ginc[b];
+            }
+            advance();
+        };
+        auto run = [&](const cplx &u, const cplx (&g)[NT]) {
+            double gr[NT], gi[NT];
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                gr[b] = g[b].x;
+                gi[b] = g[b].y;
+            }
+            mfma(u.x, u.y, gr, gi);
+        };
+        cplx u0, u1, u2 = c_make(0.0, 0.0), g0[NT], g1[NT], g2[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) g2[b] = c_make(0.0, 0.0);
+        if (ks < ks_tail) {
+            load(u0, g0);
+            load(u1, g1);
+        }
+        for (; ks < ks_tail; ks += 3) {
+            if (ks + 2 < ks_tail) load(u2, g2);
+            __builtin_amdgcn_sched_barrier(0);
+            run(u0, g0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 3 < ks_tail) load(u0, g0);
+            __builtin_amdgcn_sched_barrier(0);
+            run(u1, g1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 4 < ks_tail) load(u1, g1);
+            __builtin_amdgcn_sched_barrier(0);
+            run(u2, g2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else
     if (ks_tail > ks_head) {
         // body: operands one k-step ahead, addresses by increments
         int ga[NT], ginc[NT];
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
-            ga[b] = colv[b] ? (k - colp[b] * D) * DG + cold[b] : n * DG;     // row n of Gs: zeros
+            ga[b] = colv[b] ? (k - colp[b] * D) * DG + cold[b] : gzero;      // row n of Gs: zeros
             ginc[b] = colv[b] ? 4 * DG : 0;
         }
         cplx u_cur = S[u_addr()], g_cur[NT];
@@ -2008,6 +2071,23 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     }
     using apply_packed_t = void (*)(const cplx *, const cplx *, int, int64_t, int, int, int, cplx *);
     apply_packed_t packed_fn = nullptr;
+    // 17 - 24 channels (20, 24: all microphones of five / six arrays): two frame phases make
+    // 2 D columns = 3 column tiles (the unpacked form's second tile is half empty: 17.5 % fewer
+    // MFMAs), with G read from global memory -- in LDS it would own the CU.  Needs 4 | D (the
+    // phases' first / last k-steps are whole k-steps).  MEASURED in round 6 and NOT the default
+    // (GSS_VARIANT apply_gglobal switches it on): 1.41 ms per utterance with the operands one
+    // k-step ahead, 1.33 with two, against 1.27 for the unpacked kernel -- one row tile per wave
+    // is 9 MFMAs per four operand loads instead of 12, and three of the four come from L2.
+    const bool apply_gglobal = apply_ph == 1 && D > 16 && 2 * D <= 48 && D % 4 == 0 && n % 4 == 0 &&
+                               gss_variant_set("apply_gglobal") && gss_variant("apply_ph", 0) == 0 &&
+                               !gss_variant_set("apply_generic");
+    if (apply_gglobal) {
+        apply_ph = 2;
+        apply_nt = 3;
+        const int fl = 64 * 2 + c + 2;
+        packed_lds = sizeof(cplx) * ((size_t)fl * (D | 1) + fl / 2 + 1);
+        packed_fn = wpe_apply_packed_kernel<2, 3, false>;
+    } else
     if (apply_ph > 1) {
         static const apply_packed_t table[3][3] = {
             {wpe_apply_packed_kernel<2, 1>, wpe_apply_packed_kernel<2, 2>, wpe_apply_packed_kernel<2, 3>},

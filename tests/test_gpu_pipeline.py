@@ -774,6 +774,9 @@ def test_kernel_variants_agree(gpu_ctx, D, monkeypatch):
                     # one array: single waves over all frames / two waves splitting them (default
                     # four), 8 staging registers per lane
                     'corr_ksplit=1', 'corr_ksplit=2', 'corr_ksplit=1,corr_stg8', 'corr_stg8',
+                    # 24 channels: two frame phases in three full column tiles with G from global
+                    # memory instead of the unpacked filter application
+                    'apply_gglobal',
                     # the EM over blocks of frequencies (long segments: Infinity-Cache
                     # residency), one and two blocks in flight, more segments per frequency
                     'em_l3_fit_mb=0,em_l3_mb=1,em_streams=1', 'em_l3_fit_mb=0,em_l3_mb=1,em_streams=2',
