@@ -1,3 +1,11 @@
+"""mvdr_solve_kernel with 256 threads against a one-wave build: the same bits?
+
+    bash tools/build_variant.sh mvdr_nt64 -DGSS_MVDR_NT=64
+    python tools/cmp_mvdr_thread_counts.py          (on a GPU box)
+
+Runs MVDR-Souden + BAN on random inputs with 4 - 29 channels and on an input with a dead channel
+(the pseudo-inverse path) under both libraries (GSS_HIP_LIBRARY) and compares outputs and
+reference channels byte for byte."""
 import os, sys, subprocess, json
 sys.path.insert(0, '.'); sys.path.insert(0, 'oracle')
 import numpy as np
