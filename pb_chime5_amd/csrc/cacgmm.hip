@@ -551,7 +551,13 @@ extern "C" int gss_debug_wcov_phase(long long *host, int entries) {
 
 // KW weight rows per launch out of the Ktot rows of W / part, starting at row k0 (the
 // M-step of more than 8 classes runs in groups).
-template <int KW, bool NORMALISE, bool SRC_FDT, bool PREFETCH = false>
+// YP: elements of the (F, D, T) tile a thread stages = ceil(D / 4) -- 8 covers every channel
+// count, 3 the D <= 12 of the prefetching form (the staging pass of a tile is instruction
+// bound: tools/wcov_trace.py at D = 12, T = 7504 gives it 1600 of a tile's 4600 cycles, and the
+// ISA shows why -- eight predicated loads and eight predicated stores, a branch around each,
+// for three live elements).
+// YEXACT: D == 4 YP (12, 20, 24 channels): every staged element is a live channel, no predicate.
+template <int KW, bool NORMALISE, bool SRC_FDT, bool PREFETCH = false, int YP = 8, bool YEXACT = false>
 __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
                                                    const double *__restrict__ W, int F,
                                                    int64_t T, int D, int NE, int nch,
@@ -634,14 +640,14 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
     // sit at the barriers waiting for its loads): the NEXT tile is fetched into registers
     // before the accumulation over the current one and written to LDS after it.
     constexpr int WPRE = (KW * EM_TILE + 255) / 256;
-    cplx ypre[8];
+    cplx ypre[YP];
     double wpre[WPRE];
     auto prefetch = [&](int64_t t0) {
         const cplx *src = Y + (int64_t)f * D * T;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < YP; ++j) {
             const int d = g + 4 * j;
-            ypre[j] = (d < D && t0 + tl < c1) ? src[(int64_t)d * T + t0 + tl] : c_make(0.0, 0.0);
+            ypre[j] = ((YEXACT || d < D) && t0 + tl < c1) ? src[(int64_t)d * T + t0 + tl] : c_make(0.0, 0.0);
         }
 #pragma unroll
         for (int j = 0; j < WPRE; ++j) {
@@ -668,9 +674,9 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
             // its first LDS store (one load per trip of a loop is a chain of round trips).
             if (!PREFETCH) prefetch(t0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < YP; ++j) {
                 const int d = g + 4 * j;
-                if (d < D) ys[d * EM_TS + tl] = ypre[j];
+                if (YEXACT || d < D) ys[d * EM_TS + tl] = ypre[j];
             }
 #pragma unroll
             for (int j = 0; j < WPRE; ++j) {
@@ -1887,13 +1893,31 @@ int launch_estep_reg_k(gss_ctx *ctx, int K, int mode, const EmArgs &a, const cpl
     return gss_fail(ctx, GSS_ERR_UNSUPPORTED, "cacgmm: K=%d", K);
 }
 
+// The tiled M-step kernel for (KW classes, D channels): with the next tile prefetched for
+// D <= mstep_prefetch_d (12), and staging exactly ceil(D / 4) elements per thread where that is
+// one of the corpus' channel counts.
+static int mstep_prefetch_max_d();
+using wcov_fn_t = void (*)(const cplx *, const double *, int, int64_t, int, int, int, int, cplx *, int,
+                           int, MsegPlan);
+template <int KW>
+wcov_fn_t mstep_kernel(int D) {
+    const bool generic = gss_variant_set("mstep_generic");     // 8 predicated elements per thread
+    if (D <= mstep_prefetch_max_d()) {
+        if (D == 12 && !generic) return wcov_kernel<KW, false, true, true, 3, true>;
+        if (D <= 12 && !generic) return wcov_kernel<KW, false, true, true, 3>;
+        return wcov_kernel<KW, false, true, true>;
+    }
+    if (D == 24 && !generic) return wcov_kernel<KW, false, true, false, 6, true>;
+    if (D == 20 && !generic) return wcov_kernel<KW, false, true, false, 5, true>;
+    return wcov_kernel<KW, false, true>;
+}
+
 // Resident workgroups of the M-step kernel on this device (static partition: one run of
 // items each).
 template <int KW>
-int mstep_resident_slots(gss_ctx *ctx, int D, bool prefetch, int *slots) {
+int mstep_resident_slots(gss_ctx *ctx, int D, int *slots) {
     const size_t lds = wcov_lds_layout(D, KW).total;
-    const void *fn = prefetch ? reinterpret_cast<const void *>(wcov_kernel<KW, false, true, true>)
-                              : reinterpret_cast<const void *>(wcov_kernel<KW, false, true>);
+    const void *fn = reinterpret_cast<const void *>(mstep_kernel<KW>(D));
     if (lds > 64 * 1024)
         GSS_HIP_CHECK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0, cus = 0;
@@ -1923,19 +1947,11 @@ int launch_mstep(gss_ctx *ctx, const EmArgs &a, const cplx *Yn, int F, int K, in
         // (cross-tile prefetch against loading the tile in place, ms per launch at T = 2169:
         // D = 10 0.113 / 0.120, D = 12 0.122 / 0.124, D = 20 0.219 / 0.207; D = 24, T = 941:
         // 0.130 / 0.118)
-        if (a.D <= mstep_prefetch_max_d()) {
-            GSS_TRY(raise_lds_limit(ctx, wcov_kernel<KW, false, true, true>, lds));
-            hipLaunchKernelGGL((wcov_kernel<KW, false, true, true>),
-                               dim3(a.mseg.S > 0 ? a.mseg.S : xcd_grid(a.nch, F)),
-                               dim3(256), lds, ctx->stream, Yn, a.W, F, a.T, a.D, a.NE, a.nch,
-                               a.chunk_frames, a.Bp, K, k0, a.mseg);
-        } else {
-            GSS_TRY(raise_lds_limit(ctx, wcov_kernel<KW, false, true>, lds));
-            const dim3 grid(a.mseg.S > 0 ? a.mseg.S : xcd_grid(a.nch, F));
-            hipLaunchKernelGGL((wcov_kernel<KW, false, true>), grid, dim3(256),
-                               lds, ctx->stream, Yn, a.W, F, a.T, a.D, a.NE, a.nch, a.chunk_frames,
-                               a.Bp, K, k0, a.mseg);
-        }
+        const wcov_fn_t fn = mstep_kernel<KW>(a.D);
+        GSS_TRY(raise_lds_limit(ctx, fn, lds));
+        hipLaunchKernelGGL(fn, dim3(a.mseg.S > 0 ? a.mseg.S : xcd_grid(a.nch, F)), dim3(256), lds,
+                           ctx->stream, Yn, a.W, F, a.T, a.D, a.NE, a.nch, a.chunk_frames, a.Bp, K, k0,
+                           a.mseg);
         GSS_LAUNCH_CHECK(ctx, "wcov_kernel");
         return GSS_OK;
     }
@@ -1984,8 +2000,8 @@ int launch_mstep_k(gss_ctx *ctx, int K, const EmArgs &a, const cplx *Yn, int F) 
     return GSS_OK;
 }
 
-int mstep_resident_slots_k(gss_ctx *ctx, int KW, int D, bool prefetch, int *slots) {
-    GSS_K_SWITCH8(KW, mstep_resident_slots<KK>(ctx, D, prefetch, slots));
+int mstep_resident_slots_k(gss_ctx *ctx, int KW, int D, int *slots) {
+    GSS_K_SWITCH8(KW, mstep_resident_slots<KK>(ctx, D, slots));
     return gss_fail(ctx, GSS_ERR_UNSUPPORTED, "cacgmm: KW=%d", KW);
 }
 
@@ -2000,7 +2016,7 @@ int mstep_plan(gss_ctx *ctx, int F, int64_t T, int D, int K, MsegPlan *plan) {
     if (D < min_d || D <= 4 || gss_variant_set("mstep_chunked")) return GSS_OK;
     const int ngroups = (K + 7) / 8, per = (K + ngroups - 1) / ngroups;
     int slots = 0;
-    GSS_TRY(mstep_resident_slots_k(ctx, per, D, D <= mstep_prefetch_max_d(), &slots));
+    GSS_TRY(mstep_resident_slots_k(ctx, per, D, &slots));
     if (gss_variant("mstep_slots", 0) > 0) slots = gss_variant("mstep_slots", 0);
     const int64_t ntile = (T + EM_TILE - 1) / EM_TILE, N = ntile * F;
     if (N >= (1LL << 30) || ntile < 1) return GSS_OK;

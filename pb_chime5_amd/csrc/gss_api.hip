@@ -50,7 +50,7 @@ const char *const kVariantKeys[] = {
     // cacgmm.hip
     "em_wgs", "estep_wpb", "estep_lds", "mstep_prefetch_d", "mstep_tiled", "mstep_plan_min_d",
     "mstep_chunked", "mstep_slots", "force_eigh", "em_unfused", "em_l3_mb", "em_l3_fit_mb",
-    "em_streams", "mstep_maxseg", "em4_cold_eigh"};
+    "em_streams", "mstep_maxseg", "em4_cold_eigh", "mstep_generic"};
 struct VariantTable {
     std::mutex lock;
     std::string text;

@@ -769,7 +769,7 @@ def test_kernel_variants_agree(gpu_ctx, D, monkeypatch):
                     # M-step in chunks instead of the static partition, the one-array EM as
                     # separate launches, block-wise accumulation and pair tiles in the
                     # correlation, the general form of the filter application; two at once
-                    'mstep_chunked', 'mstep_slots=100', 'em_unfused', 'corr_blocked', 'corr_ts=3',
+                    'mstep_chunked', 'mstep_slots=100', 'em_unfused', 'corr_blocked', 'corr_ts=3', 'mstep_generic',
                     'apply_generic', 'corr_p_tiles', 'estep_lds,force_eigh,corr_ts=3',
                     # one array: single waves over all frames / two waves splitting them (default
                     # four), 8 staging registers per lane
