@@ -17,7 +17,9 @@
  *  - no C++ types, no exceptions, no torch types cross this boundary.
  *  - one gss_ctx per GPU (per host thread); a context is not thread-safe,
  *    different contexts are independent.  All work of a context is ordered on
- *    one HIP stream (its own, or one adopted with gss_set_stream()).
+ *    one HIP stream (its own, or one adopted with gss_set_stream()); a second
+ *    stream the fused pipeline may use inside a call is forked from and joined to
+ *    it by events (gss_set_utterances_in_flight()).
  *  - the caller owns every buffer it passes in.  Pointers named *_dev are device
  *    pointers valid on the context's GPU (from gss_dev_malloc(), or any other
  *    allocator of the same process, e.g. torch); pointers named *_host are host
@@ -67,7 +69,7 @@ typedef enum {
  * or a struct its layout (round 2 added `psd_context` to gss_wpe and `wpe_psd_context` to
  * gss_params: revision 2; rounds 3, 4 and 5 added entry points only: revisions 3, 4, 5).  A binder compares
  * gss_abi_version() with the GSS_ABI_VERSION it was written against before any other call. */
-#define GSS_ABI_VERSION 5
+#define GSS_ABI_VERSION 6
 int gss_abi_version(void);
 
 /* ---- context ----------------------------------------------------------- */
@@ -86,6 +88,15 @@ const char *gss_version(void);
 /* Adopt an existing hipStream_t (e.g. torch's current stream); NULL restores the
  * context's own stream. */
 int gss_set_stream(gss_ctx *ctx, void *hip_stream);
+/* How many utterances the caller keeps in flight on this context's GPU (over all of its
+ * contexts); 0 = not said (the default).  Exactly 1 -- one utterance at a time, the loop of
+ * Enhancer.enhance_example, /root/reference/pb_chime5/core.py:363-392 -- lets
+ * gss_enhance_observation*() run the two halves of the frequencies of the WPE stage side by
+ * side on a second, internal stream: one half's solve under the other's correlation, the same
+ * bits, the utterance ~1.5 % sooner.  With two or more utterances in flight (the session
+ * driver) they already fill each other's idle time; with 0 the call stays on the context's
+ * stream alone as well (and per-kernel timings mean what they say).  GSS_ERR_INVALID for n < 0. */
+int gss_set_utterances_in_flight(gss_ctx *ctx, int n);
 int gss_synchronize(gss_ctx *ctx);
 
 /* ---- device memory plumbing (for hosts that have no allocator) ---------- */

@@ -650,9 +650,16 @@ class Enhancer:
         if self.bf_drop_context:
             start_ctx, end_ctx = start_end_context_samples(ex)
         params = self._params()     # raises NotImplementedError for unknown bf / postfilter
-        res = ops.enhance_observation(
-            obs, activity, target_speaker_index, start_ctx, end_ctx, params=params,
-            debug=debug, ctx=self._ctx())
+        # one utterance at a time (this method is the loop body of core.py:363-392): the fused
+        # call may put half of the WPE stage's frequencies on the context's second stream
+        ctx = self._ctx()
+        ctx.set_utterances_in_flight(1)
+        try:
+            res = ops.enhance_observation(
+                obs, activity, target_speaker_index, start_ctx, end_ctx, params=params,
+                debug=debug, ctx=ctx)
+        finally:
+            ctx.set_utterances_in_flight(0)
         if not debug:
             return res
         x_hat, details = res

@@ -2143,13 +2143,6 @@ struct StreamRestore {
     hipStream_t s;
     ~StreamRestore() { ctx->stream = s; }
 };
-int aux_stream_ready(gss_ctx *ctx) {
-    if (!ctx->aux_stream)
-        GSS_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-    if (!ctx->ev_fork) GSS_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    if (!ctx->ev_join) GSS_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    return GSS_OK;
-}
 }   // namespace
 
 int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8_t *act,

@@ -46,7 +46,7 @@ namespace {
 const char *const kVariantKeys[] = {
     // wpe.hip
     "corr_ts", "corr_nw", "corr_blocked", "corr_p_tiles", "chol_diag_unfolded", "apply_ph",
-    "apply_generic", "prof_detail", "corr_stg8", "corr_ksplit", "apply_gglobal",
+    "apply_generic", "prof_detail", "corr_stg8", "corr_ksplit", "apply_gglobal", "wpe_halves",
     // cacgmm.hip
     "em_wgs", "estep_wpb", "estep_lds", "mstep_prefetch_d", "mstep_tiled", "mstep_plan_min_d",
     "mstep_chunked", "mstep_slots", "force_eigh", "em_unfused", "em_l3_mb", "em_l3_fit_mb",
@@ -217,10 +217,25 @@ extern "C" int gss_destroy(gss_ctx *ctx) {
     return GSS_OK;
 }
 
+int aux_stream_ready(gss_ctx *ctx) {
+    if (!ctx->aux_stream)
+        GSS_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    if (!ctx->ev_fork) GSS_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    if (!ctx->ev_join) GSS_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    return GSS_OK;
+}
+
 extern "C" int gss_set_stream(gss_ctx *ctx, void *hip_stream) {
     GSS_ENTER(ctx);
     GSS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return GSS_OK;
+}
+
+extern "C" int gss_set_utterances_in_flight(gss_ctx *ctx, int n) {
+    if (!ctx) return GSS_ERR_INVALID;
+    GSS_REQUIRE(ctx, n >= 0, GSS_ERR_INVALID, "gss_set_utterances_in_flight: n=%d", n);
+    ctx->utterances_in_flight = n;
     return GSS_OK;
 }
 
@@ -683,7 +698,7 @@ static size_t pipeline_workspace(const gss_params *p, int F, int64_t T, int64_t 
     b += align_up(sizeof(cplx) * (size_t)F * T);             // Xhat
     b += 4096;
     size_t stage = 0;
-    if (p->wpe) stage = std::max(stage, wpe_workspace_bytes(F, T, D, p->wpe_taps, p->wpe_delay));
+    if (p->wpe) stage = std::max(stage, wpe_workspace_bytes(F, T, D, p->wpe_taps, p->wpe_delay) + (1 << 16));
     stage = std::max(stage, cacgmm_workspace_bytes(F, T, D, K));
     stage = std::max(stage, mvdr_workspace_bytes(F, T, D));
     stage = std::max(stage, stft_workspace_bytes(T, p->stft_size));
@@ -740,7 +755,39 @@ static int enhance_observation_impl(gss_ctx *ctx, const gss_params *p, const voi
     GSS_TRY(stft_run(ctx, obs, obs_type, D, N, fading, Y));
     if (!p->wpe)    // no solve in this call: clear the count an earlier utterance left behind
         GSS_HIP_CHECK(ctx, hipMemsetAsync(ctx->status_dev + 2, 0, sizeof(int32_t), ctx->stream));
-    if (p->wpe) {
+    // The caller said "one utterance at a time on this GPU" (gss_set_utterances_in_flight(ctx, 1)):
+    // the WPE stage runs as two sets of frequencies side by side on the context's stream and
+    // its internal second stream -- one set's solve (a chain of latency-bound launches, MFMA
+    // busy 0.3) under the other's correlation.  Frequencies are independent: the same bits.
+    // Measured +1.1 ... +2.1 % at 4 / 12 / 20 / 24 channels for a single utterance and -1.6 %
+    // when two utterances are in flight anyway (EXPERIMENTS round 6, item 8), hence the hint;
+    // not the default because overlapped launches no longer have durations of their own (the
+    // per-kernel table and the roofline of a profile are taken on one stream).  GSS_VARIANT
+    // wpe_halves=0 / 1 forces it off / on, wpe_halves=n (n > 1) puts 8 n frequencies into the
+    // first set.
+    const int halves = gss_variant("wpe_halves", ctx->utterances_in_flight == 1 ? 1 : 0);
+    if (p->wpe && halves > 0 && F >= 32 && p->wpe_iterations > 0) {
+        GSS_TRY(aux_stream_ready(ctx));
+        hipStream_t const main_stream = ctx->stream;
+        const int F0 = halves > 1 ? std::min(halves * 8, F - 8) : (F / 2 + 7) / 8 * 8, F1 = F - F0;
+        const size_t off = (size_t)F0 * T * D;
+        int st = wpe_run(ctx, Y, F0, T, D, p->wpe_taps, p->wpe_delay, p->wpe_iterations,
+                         p->wpe_psd_context, X, 0);
+        if (st == GSS_OK) {
+            GSS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+            ctx->stream = ctx->aux_stream;
+            st = wpe_run(ctx, Y + off, F1, T, D, p->wpe_taps, p->wpe_delay, p->wpe_iterations,
+                         p->wpe_psd_context, X + off, 1);
+            ctx->stream = main_stream;
+            // (joined even when the second part failed to enqueue: nothing may be left running
+            // on the internal stream when the call returns)
+            GSS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
+            GSS_HIP_CHECK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+        }
+        GSS_TRY(st);
+        GSS_TRY(wpe_copy_zero_pivots(ctx));
+        ctx->arena_off = mark;
+    } else if (p->wpe) {
         GSS_TRY(wpe_run(ctx, Y, F, T, D, p->wpe_taps, p->wpe_delay, p->wpe_iterations,
                         p->wpe_psd_context, X));
         ctx->arena_off = mark;

@@ -145,6 +145,7 @@ struct gss_ctx {
     // flight), forked from / joined to `stream` by events; created on first use
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int utterances_in_flight = 0;   // gss_set_utterances_in_flight(): exactly 1 = a call may use aux_stream
     std::string error;
 
     // bump arena for intermediates of one top-level call
@@ -233,8 +234,16 @@ struct ProfScope {
 size_t wpe_workspace_bytes(int F, int64_t T, int D, int taps, int delay);
 int wpe_inverse_power_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int psd_context,
                           double *w);
+// part: -1 = the whole call; 0 / 1 = one of two sets of frequencies that run side by side on
+// ctx->stream / ctx->aux_stream (gss_enhance_observation, GSS_VARIANT wpe_halves): part 0 zeroes
+// the pivot counter and records ctx->ev_fork behind it, neither part copies the count to the
+// host, each has its own correlation work queues.
 int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int delay,
-            int iterations, int psd_context, cplx *X);
+            int iterations, int psd_context, cplx *X, int part = -1);
+// the pivot count of the last wpe_run parts -> the context's status word (after the join)
+int wpe_copy_zero_pivots(gss_ctx *ctx);
+// second stream + fork / join events of a context, created on first use
+int aux_stream_ready(gss_ctx *ctx);
 
 size_t cacgmm_workspace_bytes(int F, int64_t T, int D, int K);
 int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8_t *act,

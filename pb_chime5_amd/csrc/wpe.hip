@@ -1867,7 +1867,7 @@ int wpe_inverse_power_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, 
 }
 
 int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int delay,
-            int iterations, int psd_context, cplx *X) {
+            int iterations, int psd_context, cplx *X, int part) {
     const int n = taps * D;
     const int c = delay + taps - 1;
     if (iterations == 0) {
@@ -1968,9 +1968,11 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
     // zeroed pivots of this call (all iterations, all frequencies): counted on the device,
     // copied to the context's status words at the end (gss_last_wpe_zero_pivots)
     int32_t *zero_pivots = reinterpret_cast<int32_t *>(tiles_dev + 1024 + 4096);
-    GSS_HIP_CHECK(ctx, hipMemsetAsync(zero_pivots, 0, sizeof(int32_t), ctx->stream));
-    // work-queue heads of the persistent correlation kernel: 8 counters, 64 bytes apart
-    int *corr_counters = reinterpret_cast<int *>(tiles_dev + 1024 + 4096 + 1);
+    if (part <= 0) GSS_HIP_CHECK(ctx, hipMemsetAsync(zero_pivots, 0, sizeof(int32_t), ctx->stream));
+    if (part == 0) GSS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    // work-queue heads of the persistent correlation kernel: 8 counters, 64 bytes apart (a second
+    // set for the second of two parts that run side by side)
+    int *corr_counters = reinterpret_cast<int *>(tiles_dev + 1024 + 4096 + 1) + (part == 1 ? 128 : 0);
 
     const int padf = corr_padf(D, 16 * corr_ts);
     // (everywhere: 3 real MFMAs per complex product -- t1 = ar br, t2 = ai bi,
@@ -2225,11 +2227,22 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
             GSS_LAUNCH_CHECK(ctx, "wpe_apply_kernel");
         }
     }
+    // (two parts: the caller copies the count after both have finished)
+    if (part < 0)
+        GSS_HIP_CHECK(ctx, hipMemcpyAsync(ctx->status_host + 2, zero_pivots, sizeof(int32_t),
+                                          hipMemcpyDeviceToHost, ctx->stream));
+    return GSS_OK;
+}
+
+
+int wpe_copy_zero_pivots(gss_ctx *ctx) {
+    if (!ctx->wpe_tiles) return GSS_OK;
+    const int32_t *zero_pivots =
+        reinterpret_cast<const int32_t *>(reinterpret_cast<const CorrTile *>(ctx->wpe_tiles) + 1024 + 4096);
     GSS_HIP_CHECK(ctx, hipMemcpyAsync(ctx->status_host + 2, zero_pivots, sizeof(int32_t),
                                       hipMemcpyDeviceToHost, ctx->stream));
     return GSS_OK;
 }
-
 
 int selftest_mfma_run(gss_ctx *ctx) {
     double *out = nullptr;

@@ -434,6 +434,8 @@ class UtterancePipeline:
         self.slots = [first] + [Context(first.device_id) for _ in range(depth - 1)]
         for c in self.slots:
             _prepare_windows(c, params.stft_size, params.stft_shift, window)
+            # (with utterances in flight beside each other a call stays on its own stream)
+            c.set_utterances_in_flight(depth)
         self._bufs = [dict() for _ in self.slots]
         self._pending = deque()
         self._next = 0
@@ -583,6 +585,10 @@ class UtterancePipeline:
                 except Exception:
                     pass
             self.slots = self.slots[:1]
+            try:        # the first slot is the caller's context: nothing said again
+                self.slots[0].set_utterances_in_flight(0)
+            except Exception:
+                pass
 
 
 def enhance_observation(obs, activity, target_index, start_context_samples,

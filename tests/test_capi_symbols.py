@@ -118,6 +118,8 @@ def test_variant_keys_are_documented_and_used():
         text = (csrc / name).read_text()
         used |= set(re.findall(r'gss_variant(?:_set)?\("([a-z0-9_]+)"', text))
         assert 'getenv' not in text, name
+    # (the fused pipeline's own switch lives in gss_api.hip, next to the one getenv of the library)
+    used |= set(re.findall(r'gss_variant(?:_set)?\("([a-z0-9_]+)"', api))
     assert used == accepted, (sorted(used - accepted), sorted(accepted - used))
     doc = (REPO / 'INTEGRATION.md').read_text()
     section = doc[doc.index('## Debug switches'):doc.index('## Replacing `mpiexec')]

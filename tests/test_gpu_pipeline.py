@@ -1073,3 +1073,50 @@ def test_random_shapes_against_oracle(gpu_ctx, ref_mismatches):
         print('fuzz:', done, 'cases;', notes)
     assert not failures, '\n'.join(failures)
     assert done >= min(15, cases // 3), done
+
+
+def test_wpe_in_two_sets_of_frequencies_gives_the_same_bits(gpu_ctx, monkeypatch):
+    """gss_set_utterances_in_flight (ABI 6): told that there is one utterance at a time on the GPU
+    (Enhancer.enhance_observation says so) the fused pipeline runs the WPE stage as two sets of frequencies side by side on
+    the context's stream and an internal second one (a set's solve under the other's
+    correlation).  Frequencies are independent: every tap of the pipeline is BIT-identical to
+    the one-stream run (hint 2 or 0, or GSS_VARIANT=wpe_halves=0), for an even and an uneven split,
+    the zeroed-pivot count of an underdetermined WPE still reaches the status word, and the
+    context is usable on one stream again afterwards."""
+    from pb_chime5_amd import ops, synthetic
+    u = synthetic.tiny(seed=61, num_channels=6, num_samples=48000, num_speakers=2, context=4096,
+                       noise=3e-2)
+    cs = u.ex['start_orig']['original']
+    ce = u.ex['end']['original'] - u.ex['end_orig']['original']
+
+    def run(**kw):
+        return ops.enhance_observation(u.obs, u.activity_array, u.target_index, cs, ce, wpe=True,
+                                       wpe_taps=3, wpe_iterations=2, bss_iterations=4, debug=True,
+                                       ctx=gpu_ctx, **kw)
+    gpu_ctx.set_utterances_in_flight(2)
+    one, d_one = run()
+    gpu_ctx.set_utterances_in_flight(1)
+    two, d_two = run()
+    monkeypatch.setenv('GSS_VARIANT', 'wpe_halves=20')
+    uneven, d_uneven = run()
+    monkeypatch.setenv('GSS_VARIANT', 'wpe_halves=0')
+    off, d_off = run()
+    monkeypatch.delenv('GSS_VARIANT')
+    for other, det in ((two, d_two), (uneven, d_uneven), (off, d_off)):
+        assert np.array_equal(other, one)
+        for key in ('Obs', 'posterior', 'X_hat', 'target_mask'):
+            assert np.array_equal(det[key], d_one[key]), key
+    assert gpu_ctx.last_wpe_zero_pivots() == 0
+    # fewer frames than unknowns: pivots are zeroed in both sets and counted once
+    short = synthetic.tiny(seed=62, num_channels=8, num_samples=9000, num_speakers=2, context=1000)
+    counts = []
+    for hint in (2, 1):
+        gpu_ctx.set_utterances_in_flight(hint)
+        ops.enhance_observation(short.obs, short.activity_array, short.target_index, 1000, 1000,
+                                wpe=True, wpe_taps=10, wpe_iterations=1, bss_iterations=2,
+                                ctx=gpu_ctx)
+        counts.append(gpu_ctx.last_wpe_zero_pivots())
+    assert counts[0] == counts[1] > 0, counts
+    with pytest.raises(ValueError):
+        gpu_ctx.set_utterances_in_flight(-1)
+    gpu_ctx.set_utterances_in_flight(0)
