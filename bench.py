@@ -607,6 +607,10 @@ def parse_args():
     ap.add_argument('--n1-value', type=float, default=None,
                     help="the same workload's `value` at --gpus 1 (a BENCH record): the line then "
                          "carries scaling_efficiency_vs_n1 = value / (N x n1) beside value_per_gpu")
+    ap.add_argument('--one-at-a-time', action='store_true',
+                    help='with --only-headline / --workload: also time the loop with the WPE stage on two '
+                         'streams (value_one_at_a_time_api); off by default so that a profile of the '
+                         'command sees one-stream launches only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-bins', type=int, default=24)
     ap.add_argument('--cpu-workers', type=int, default=None)
@@ -1025,7 +1029,7 @@ def main():
     # streams (gss_set_utterances_in_flight(ctx, 1); same bits).  NOT the headline: overlapped
     # launches have no durations of their own, the kernel table and `roofline` are one-stream.
     one_at_a_time = None
-    if extras or args.workload != '2':
+    if extras or args.one_at_a_time:
         ctx.set_utterances_in_flight(1)
         for _ in range(2):
             step()
