@@ -1120,3 +1120,42 @@ def test_wpe_in_two_sets_of_frequencies_gives_the_same_bits(gpu_ctx, monkeypatch
     with pytest.raises(ValueError):
         gpu_ctx.set_utterances_in_flight(-1)
     gpu_ctx.set_utterances_in_flight(0)
+
+
+def test_adopted_stream_and_profiling_with_the_second_stream(gpu_ctx):
+    """gss_set_stream + gss_profile_*: the fused pipeline on a stream the caller owns,
+    with the per-kernel profile switched on, one stream and two (gss_set_utterances_in_flight 1):
+    the same bits as on the context's own stream; the profile of the two-stream run lists twice
+    the WPE launches (two sets of frequencies) and the same EM launches; the caller's stream is
+    what the result is ordered on (no synchronisation of ours in between)."""
+    import ctypes
+    from pb_chime5_amd import ops, synthetic
+    u = synthetic.tiny(seed=71, num_channels=5, num_samples=30000, num_speakers=2, context=3000)
+    kw = dict(wpe=True, wpe_taps=3, wpe_iterations=2, bss_iterations=3, ctx=gpu_ctx)
+
+    def run():
+        return ops.enhance_observation(u.obs, u.activity_array, u.target_index, 3000, 3000, **kw)
+    want = run()
+    hip = ctypes.CDLL('libamdhip64.so')          # a stream of the caller's own
+    stream = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(stream)) == 0
+    gpu_ctx.set_stream(stream.value)
+    try:
+        calls = {}
+        for hint in (0, 1):
+            gpu_ctx.set_utterances_in_flight(hint)
+            gpu_ctx.profile_enable(True)
+            gpu_ctx.profile_reset()
+            got = run()
+            prof = gpu_ctx.profile_report()
+            gpu_ctx.profile_enable(False)
+            assert np.array_equal(got, want), hint
+            calls[hint] = {k: v['calls'] for k, v in prof.items()}
+        assert calls[1]['wpe_corr'] == 2 * calls[0]['wpe_corr'] == 4
+        assert calls[1]['wpe_apply'] == 2 * calls[0]['wpe_apply']
+        assert calls[1]['em_estep'] == calls[0]['em_estep'] and calls[1]['stft'] == calls[0]['stft'] == 1
+    finally:
+        gpu_ctx.set_utterances_in_flight(0)
+        gpu_ctx.set_stream(None)
+        hip.hipStreamDestroy(stream)
+    assert np.array_equal(run(), want)
