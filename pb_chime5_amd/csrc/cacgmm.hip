@@ -98,7 +98,9 @@ struct EmArgs {
 // Load frames [t0, t0+64) of one frequency into LDS as ys[d][tl], optionally unit
 // normalised per frame (pb_bss normalize_observation).  `scratch` holds 4 * 64
 // doubles.  Thread (tl, g) loads channels d = g, g+4, ...
-template <bool NORMALISE>
+// NV: elements of the 64 x D tile per thread = ceil(D / 4) (8 covers D <= 32; callers that know
+// their channel count pass the exact number: the pass is a row of predicated loads and stores)
+template <bool NORMALISE, int NV = 8>
 __device__ __forceinline__ void load_tile(const cplx *Yf, int D, int64_t t0, int64_t c1, int tl,
                                           int g, cplx *ys, double *scratch) {
     // The 64 x D elements of the tile are one contiguous run of the (T, D) slab: consecutive
@@ -110,16 +112,16 @@ __device__ __forceinline__ void load_tile(const cplx *Yf, int D, int64_t t0, int
     const int total = nfr * D;
     const cplx *src = Yf + t0 * D;
     const int qf = 256 / D, rf = 256 - qf * D;
-    cplx v[8];   // D <= 32 -> at most 8 elements per thread
+    cplx v[NV];   // D <= 4 NV
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NV; ++j) {
         const int idx = tid + 256 * j;
         v[j] = idx < total ? src[idx] : c_make(0.0, 0.0);
     }
     {
         int fr = tid / D, d = tid - fr * D;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NV; ++j) {
             if (tid + 256 * j < EM_TILE * D) ys[d * EM_TS + fr] = v[j];     // (zeros past the last frame)
             fr += qf;
             d += rf;
@@ -135,7 +137,7 @@ __device__ __forceinline__ void load_tile(const cplx *Yf, int D, int64_t t0, int
         // the groups in order -- the summation order of the loader this one replaces
         double nrm = 0.0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int d = g + 4 * j;
             nrm += d < D ? c_abs2(ys[d * EM_TS + tl]) : 0.0;
         }
@@ -146,7 +148,7 @@ __device__ __forceinline__ void load_tile(const cplx *Yf, int D, int64_t t0, int
         nrm = sqrt(nrm);
         if (nrm == 0.0) nrm = GSS_TINY;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int d = g + 4 * j;
             if (d < D) {
                 const cplx y = ys[d * EM_TS + tl];
@@ -316,6 +318,7 @@ __global__ __launch_bounds__(256) void em_estep_kernel(EmArgs a, const cplx *__r
 // one frame, pulls its D channel values with coalesced loads into registers, walks the
 // packed upper triangle fully unrolled with the model row in SGPRs (scalar loads), and
 // finishes the softmax in registers.  Lanes never exchange data.
+template <int NV>
 __global__ __launch_bounds__(256) void em_prepare_kernel(const cplx *__restrict__ Y, int F,
                                                          int64_t T, int D,
                                                          cplx *__restrict__ Yn) {
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(256) void em_prepare_kernel(const cplx *__restrict_
     if (!xcd_group_map((int)((T + EM_TILE - 1) / EM_TILE), F, f, tile)) return;
     const int tid = threadIdx.x, tl = tid & 63, g = tid >> 6;
     const int64_t t0 = (int64_t)tile * EM_TILE;
-    load_tile<true>(Y + (int64_t)f * T * D, D, t0, T, tl, g, ys, scratch);
+    load_tile<true, NV>(Y + (int64_t)f * T * D, D, t0, T, tl, g, ys, scratch);
     __syncthreads();
     const int64_t t = t0 + tl;
     if (t < T)
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(256) void wcov_kernel(const cplx *__restrict__ Y,
             __syncthreads();
             if (PREFETCH && t0 + EM_TILE < c1) prefetch(t0 + EM_TILE);
         } else {
-            load_tile<NORMALISE>(Yf, D, t0, c1, tl, g, ys, scratch);
+            load_tile<NORMALISE, YP>(Yf, D, t0, c1, tl, g, ys, scratch);
             for (int idx = tid; idx < KW * EM_TILE; idx += blockDim.x) {
                 const int k = idx / EM_TILE, j = idx - k * EM_TILE;
                 wk[idx] = t0 + j < c1 ? Wf[(int64_t)k * T + t0 + j] : 0.0;
@@ -2100,8 +2103,12 @@ EmStrides em_strides(const EmBlockPlan &p, int F, int64_t T, int D) {
 int psd_partials_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const double *W2,
                      int nch, int chunk_frames, cplx *part) {
     const size_t lds = wcov_lds_layout(D, 2).total;
-    GSS_TRY(raise_lds_limit(ctx, wcov_kernel<2, false, false>, lds));
-    hipLaunchKernelGGL((wcov_kernel<2, false, false>), dim3(xcd_grid(nch, F)), dim3(256), lds,
+    // (the tile pass of the (F, T, D) layout with exactly as many slots as the channel count needs)
+    const wcov_fn_t fn = D <= 4 ? wcov_kernel<2, false, false, false, 1>
+                         : D <= 12 ? wcov_kernel<2, false, false, false, 3>
+                         : D <= 24 ? wcov_kernel<2, false, false, false, 6> : wcov_kernel<2, false, false>;
+    GSS_TRY(raise_lds_limit(ctx, fn, lds));
+    hipLaunchKernelGGL(fn, dim3(xcd_grid(nch, F)), dim3(256), lds,
                        ctx->stream, Y, W2, F, T, D, tri_count(D), nch, chunk_frames, part, 2, 0,
                        MsegPlan{});
     GSS_LAUNCH_CHECK(ctx, "wcov_kernel");
@@ -2220,7 +2227,9 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     auto prepare = [&](EmBlock &b) -> int {
         GSS_PROF(ctx, "em_prepare");
         const size_t plds = sizeof(cplx) * (size_t)D * EM_TS + sizeof(double) * 4 * EM_TILE;
-        hipLaunchKernelGGL(em_prepare_kernel,
+        const auto prep = D <= 4 ? em_prepare_kernel<1> : D <= 12 ? em_prepare_kernel<3>
+                          : D <= 24 ? em_prepare_kernel<6> : em_prepare_kernel<8>;
+        hipLaunchKernelGGL(prep,
                            dim3(xcd_grid((int)((T + EM_TILE - 1) / EM_TILE), b.F)), dim3(256), plds,
                            ctx->stream, b.a.Y, b.F, T, D, b.Yn);
         GSS_LAUNCH_CHECK(ctx, "em_prepare_kernel");

@@ -914,24 +914,10 @@ __device__ inline void chol_panel_tile(cplx *A, cplx *Z, int n, int D, int j0, i
         }
 }
 
-// grid (ceil(tiles / 4), F), block 256: every workgroup stages the factored diagonal
-// block of its frequency in LDS, then each wave takes one column tile.
-__global__ __launch_bounds__(256) void chol_trsm_kernel(cplx *__restrict__ R,
-                                                        cplx *__restrict__ P, int F, int n,
-                                                        int D, int j0) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    cplx *Ud = reinterpret_cast<cplx *>(smem);                       // CH_NB * UD_LD
-    double *dinv = reinterpret_cast<double *>(Ud + CH_NB * UD_LD);   // CH_NB
+// The factored diagonal block (U_JJ above, W below the diagonal) -> LDS, 1 / U_ii -> dinv, by
+// 256 threads: all 9 loads of a thread in flight before the first store.
+__device__ inline void chol_stage_diag(const cplx *A, int n, int j0, int nb, cplx *Ud, double *dinv) {
     const int tid = threadIdx.x;
-    const int nb = min(CH_NB, n - j0);
-    const int ntrail = n - j0 - nb;
-    const int npanel = (ntrail + 15) / 16 + (D + 15) / 16;
-    int f, grp;       // the workgroups of one frequency share one XCD (one L2)
-    if (!xcd_group_map((npanel + 3) / 4, F, f, grp)) return;
-    cplx *A = R + (int64_t)f * n * n;
-    cplx *Z = P + (int64_t)f * n * D;
-    // diagonal block (U_JJ above, W below the diagonal) -> LDS: all 9 loads of a thread in
-    // flight before the first store
     constexpr int WL = CH_NB * CH_NB / 256;
     static_assert(WL * 256 == CH_NB * CH_NB, "block size");
     cplx wv[WL];
@@ -949,6 +935,25 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(cplx *__restrict__ R,
         Ud[i * UD_LD + k] = wv[s];
         if (k == i) dinv[i] = wv[s].x > 0.0 ? 1.0 / wv[s].x : 0.0;
     }
+}
+
+// grid (ceil(tiles / 4), F), block 256: every workgroup stages the factored diagonal
+// block of its frequency in LDS, then each wave takes one column tile.
+__global__ __launch_bounds__(256) void chol_trsm_kernel(cplx *__restrict__ R,
+                                                        cplx *__restrict__ P, int F, int n,
+                                                        int D, int j0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx *Ud = reinterpret_cast<cplx *>(smem);                       // CH_NB * UD_LD
+    double *dinv = reinterpret_cast<double *>(Ud + CH_NB * UD_LD);   // CH_NB
+    const int tid = threadIdx.x;
+    const int nb = min(CH_NB, n - j0);
+    const int ntrail = n - j0 - nb;
+    const int npanel = (ntrail + 15) / 16 + (D + 15) / 16;
+    int f, grp;       // the workgroups of one frequency share one XCD (one L2)
+    if (!xcd_group_map((npanel + 3) / 4, F, f, grp)) return;
+    cplx *A = R + (int64_t)f * n * n;
+    cplx *Z = P + (int64_t)f * n * D;
+    chol_stage_diag(A, n, j0, nb, Ud, dinv);
     __syncthreads();
     const int ct = grp * 4 + (tid >> 6);
     if (ct < npanel) chol_panel_tile(A, Z, n, D, j0, nb, ct, Ud, dinv, tid & 63);
@@ -1514,7 +1519,11 @@ __global__ __launch_bounds__(64 * NWV) void wpe_apply_kernel(const cplx *__restr
 // a CU alone at these channel counts (1.82 vs 1.35 ms in round 4); the operands are requested
 // two k-steps (18 MFMAs) ahead.  Opt-in (GSS_VARIANT apply_gglobal): measured slower than the
 // unpacked kernel, see wpe_run.
-template <int PH, int NT, bool GLDS = true>
+// PREW / PREG: elements per thread of the staging passes (window, G).  14 covers every shape;
+// one array (820 window elements, 160 of G) needs 4 and 1 -- the kernel is 36 MFMAs per wave
+// behind two staging passes, and at 14 predicated slots each those passes were 1170 of its 1857
+// instructions (tools/isa_scratch_by_loop.py).
+template <int PH, int NT, bool GLDS = true, int PREW = 14, int PREG = 14>
 __global__ __launch_bounds__(256) void wpe_apply_packed_kernel(const cplx *__restrict__ Y,
                                                                const cplx *__restrict__ G, int F,
                                                                int64_t T, int D, int n, int c,
@@ -1531,8 +1540,9 @@ __global__ __launch_bounds__(256) void wpe_apply_packed_kernel(const cplx *__res
     const cplx *Yf = Y + (int64_t)f * T * D;
     const cplx *Gf = G + (int64_t)f * n * D;
     const int64_t fr0 = t0 - c;
-    constexpr int PRE = 14, NTHR = 256;
+    constexpr int NTHR = 256;
     {   // window -> LDS (all loads of a batch in flight before the first store)
+        constexpr int PRE = PREW;
         const int total = frames_lds * D;
         for (int base = 0; base < total; base += NTHR * PRE) {
             cplx v[PRE];
@@ -1552,6 +1562,7 @@ __global__ __launch_bounds__(256) void wpe_apply_packed_kernel(const cplx *__res
         }
     }
     if (GLDS) {   // G -> LDS
+        constexpr int PRE = PREG;
         cplx *Gs = Gl;
         const int total = n * D;
         for (int base = 0; base < total; base += NTHR * PRE) {
@@ -2096,6 +2107,13 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
             {wpe_apply_packed_kernel<3, 1>, wpe_apply_packed_kernel<3, 2>, wpe_apply_packed_kernel<3, 3>},
             {wpe_apply_packed_kernel<4, 1>, wpe_apply_packed_kernel<4, 2>, wpe_apply_packed_kernel<4, 3>}};
         packed_fn = table[apply_ph - 2][apply_nt - 1];
+        // few staged elements per thread (one array): the form with 4 + 1 staging slots
+        static const apply_packed_t table_small[3][3] = {
+            {wpe_apply_packed_kernel<2, 1, true, 4, 1>, wpe_apply_packed_kernel<2, 2, true, 4, 1>, wpe_apply_packed_kernel<2, 3, true, 4, 1>},
+            {wpe_apply_packed_kernel<3, 1, true, 4, 1>, wpe_apply_packed_kernel<3, 2, true, 4, 1>, wpe_apply_packed_kernel<3, 3, true, 4, 1>},
+            {wpe_apply_packed_kernel<4, 1, true, 4, 1>, wpe_apply_packed_kernel<4, 2, true, 4, 1>, wpe_apply_packed_kernel<4, 3, true, 4, 1>}};
+        if ((64 * apply_ph + c + 2) * D <= 4 * 256 && n * D <= 256 && !gss_variant_set("apply_generic"))
+            packed_fn = table_small[apply_ph - 2][apply_nt - 1];
         if (packed_lds > 64 * 1024)
             GSS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(packed_fn),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -13,13 +13,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 bench() { python $R/bench.py --only-headline $W "$@"; }
-if [ -z "$W" ]; then
-  # the full default line (session mode, configs table, sharded config 3, CPU baseline) ...
-  python $R/bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err
-fi
-# ... and the headline alone: the command every profile below is taken with (back-to-back
-# launches of ONE stream and ONE shape, so that per-kernel averages mean something)
-bench > $O/bench_${TAG}_headline.json 2>> $O/bench_$TAG.err
+: > $O/bench_$TAG.err
 rm -rf $O/prof_stats_$TAG $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmcM $O/pmcA $O/pmcB
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_$TAG -o $TAG -- python $R/bench.py --only-headline $W > $O/prof_stats_$TAG.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -32,9 +26,24 @@ rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUS
 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VMEM SQ_WAVE_CYCLES \
   --kernel-trace --output-format csv -d $O/pmcB -o p -- python $R/bench.py --only-headline $W --steps 1 --warmup 1 > $O/pmcB.log 2>&1
 cd $R
-tail -1 $O/bench_${TAG}_headline.json | cut -c1-300
 find $O/prof_stats_$TAG -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_$TAG.csv \;
 python tools/pmc_traffic.py $O $O/traffic_$TAG.json
+# The bench lines come LAST: `roofline.traffic` is read from profiles/traffic*.json and only
+# accepted when that file was measured on the sources of the loaded library -- so the figure of
+# THIS run is put where bench.py looks (on the box's copy of the tree; copy it back by hand).
+case "$W" in
+  "") TF=traffic.json ;;
+  *) TF=traffic_$(echo $W | sed 's/.*--workload \([^ ]*\).*/\1/').json ;;
+esac
+cp $O/traffic_$TAG.json $R/profiles/$TF
+# the headline alone: the command every profile above was taken with (back-to-back launches of
+# ONE stream and ONE shape, so that per-kernel averages mean something) ...
+(cd /tmp && bench) > $O/bench_${TAG}_headline.json 2>> $O/bench_$TAG.err
+if [ -z "$W" ]; then
+  # ... and the full default line (session mode, configs table, sharded config 3, CPU baseline)
+  (cd /tmp && python $R/bench.py) > $O/bench_$TAG.json 2>> $O/bench_$TAG.err
+fi
+tail -n 1 $O/bench_${TAG}_headline.json | cut -c1-300
 cc() { find $O/$1 -name "*counter_collection.csv" | head -1; }
 kt() { find $O/$1 -name "*kernel_trace.csv" | head -1; }
 python tools/pmc_mfma.py $(cc pmcM) $(kt pmcM) > $O/mfma_util_$TAG.txt; cat $O/mfma_util_$TAG.txt
