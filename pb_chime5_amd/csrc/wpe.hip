@@ -830,6 +830,20 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(cplx *__restrict__ R, in
     chol_diag_block(R + (int64_t)blockIdx.x * n * n, n, j0, Ud, dinv, zero_pivots);
 }
 
+// LDS copy of a factored diagonal block for the row panel: block row b (16 rows) keeps its
+// columns from 16 b on -- U above the diagonal and, inside the three diagonal 16 x 16 blocks, W
+// below it; the three blocks under the block diagonal are never read.  96 instead of 144 rows of
+// 16: 25.7 KB with the reciprocal diagonal instead of 38 KB, i.e. FIVE workgroups per CU where
+// LDS allowed four -- and four are 1024 slots for the 1026 workgroups (2 x 513) that the third
+// and the fourth block column of the 24-channel solve launch: a second round for two of them.
+// Odd leading dimensions (49, 33, 17 complex): the 16 lanes of a fragment row hit 16 bank groups.
+constexpr int UDP_SIZE = 16 * (CH_NB + 1) + 16 * (CH_NB - 16 + 1) + 16 * (CH_NB - 32 + 1);
+__device__ __forceinline__ int udp_off(int row, int col) {
+    const int b = row >> 4;
+    const int base = b == 0 ? 0 : b == 1 ? 16 * (CH_NB + 1) : 16 * (CH_NB + 1) + 16 * (CH_NB - 16 + 1);
+    return base + (row & 15) * (CH_NB - 16 * b + 1) + col - 16 * b;
+}
+
 // Row panel on the MFMA: U_J[:, tile] = U_JJ^-H A_J[:, tile] for one tile `ct` of 16 trailing
 // columns (tiles past the trailing block address the right-hand sides), by one wave.
 // Forward substitution in 16-row blocks with the EXPLICIT INVERSES OF THE 16 x 16 DIAGONAL
@@ -883,7 +897,7 @@ __device__ inline void chol_panel_tile(cplx *A, cplx *Z, int n, int D, int j0, i
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int k = 16 * jt + 4 * ks + lk;
-                const cplx u = Ud[k * UD_LD + i];
+                const cplx u = Ud[udp_off(k, i)];
                 // T -= conj(u) x
                 tre = __builtin_amdgcn_mfma_f64_16x16x4f64(-u.x, xre[jt][ks], tre, 0, 0, 0);
                 tim = __builtin_amdgcn_mfma_f64_16x16x4f64(-u.x, xim[jt][ks], tim, 0, 0, 0);
@@ -896,7 +910,7 @@ __device__ inline void chol_panel_tile(cplx *A, cplx *Z, int n, int D, int j0, i
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int k = 16 * it + 4 * ks + lk;
-            cplx w = Ud[i * UD_LD + k];
+            cplx w = Ud[udp_off(i, k)];
             if (k == i) w = c_make(i < nb ? dinv[i] : 0.0, 0.0);
             if (k > i) w = c_make(0.0, 0.0);
             xre[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, tre[ks], xre[it], 0, 0, 0);
@@ -926,13 +940,13 @@ __device__ inline void chol_stage_diag(const cplx *A, int n, int j0, int nb, cpl
         const int idx = tid + 256 * s;
         const int i = idx / CH_NB, k = idx - i * CH_NB;
         wv[s] = c_make(0.0, 0.0);
-        if (i < nb && k < nb) wv[s] = A[(int64_t)(j0 + i) * n + j0 + k];
+        if (i < nb && k < nb && k >= (i & ~15)) wv[s] = A[(int64_t)(j0 + i) * n + j0 + k];
     }
 #pragma unroll
     for (int s = 0; s < WL; ++s) {
         const int idx = tid + 256 * s;
         const int i = idx / CH_NB, k = idx - i * CH_NB;
-        Ud[i * UD_LD + k] = wv[s];
+        if (k >= (i & ~15)) Ud[udp_off(i, k)] = wv[s];
         if (k == i) dinv[i] = wv[s].x > 0.0 ? 1.0 / wv[s].x : 0.0;
     }
 }
@@ -943,8 +957,8 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(cplx *__restrict__ R,
                                                         cplx *__restrict__ P, int F, int n,
                                                         int D, int j0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cplx *Ud = reinterpret_cast<cplx *>(smem);                       // CH_NB * UD_LD
-    double *dinv = reinterpret_cast<double *>(Ud + CH_NB * UD_LD);   // CH_NB
+    cplx *Ud = reinterpret_cast<cplx *>(smem);                       // UDP_SIZE (udp_off)
+    double *dinv = reinterpret_cast<double *>(Ud + UDP_SIZE);        // CH_NB
     const int tid = threadIdx.x;
     const int nb = min(CH_NB, n - j0);
     const int ntrail = n - j0 - nb;
@@ -2027,8 +2041,7 @@ int wpe_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, int taps, int 
                               : (corr_ks == 2 ? wpe_corr_ksplit_kernel<2, 8> : wpe_corr_ksplit_kernel<4, 8>);
         corr_lds = std::max(corr_lds * corr_ks, sizeof(cplx) * 256 * (size_t)(corr_ks - 1));
     }
-    const size_t panel_lds = sizeof(cplx) * CH_NB * UD_LD + sizeof(double) * CH_NB;
-    static_assert(BS_LD <= UD_LD, "S must fit in Ud");
+    const size_t panel_lds = sizeof(cplx) * UDP_SIZE + sizeof(double) * CH_NB;
     constexpr int apply_ta = 2;
     constexpr int apply_nwv = 4;       // (2 or 3 waves per workgroup: 1.41 / 1.47 vs 1.37 ms, round 4)
     const int apply_frames = 16 * apply_ta * apply_nwv;
