@@ -288,9 +288,13 @@ def wpe_block(Obs, taps=10, delay=2, iterations=3, psd_context=0):
 # CACGMM  (pb_bss.distribution.CACGMMTrainer / CACGMM; core.py:154-214)
 # --------------------------------------------------------------------------
 def normalize_observation(y):
-    """(..., T, D) -> (..., D, T), unit norm per frame ('where' eps style)."""
+    """(..., T, D) -> (..., D, T), unit norm per frame: y / maximum(norm, tiny), as upstream's
+    ``normalize_observation`` writes it (a frame whose norm is a denormal number is divided by
+    tiny, not by its norm; NaN stays NaN; with sqrt(sum |y|^2) a norm in (0, tiny) cannot
+    occur at all -- the squares underflow first -- so this equals the 'where' eps style on every
+    float64 input)."""
     norm = np.linalg.norm(y, axis=-1, keepdims=True)
-    norm = np.where(norm == 0, TINY, norm)
+    norm = np.maximum(norm, TINY)
     return np.ascontiguousarray(np.swapaxes(y / norm, -2, -1))
 
 

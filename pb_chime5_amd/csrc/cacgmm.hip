@@ -146,7 +146,7 @@ __device__ __forceinline__ void load_tile(const cplx *Yf, int D, int64_t t0, int
         nrm = scratch[tl] + scratch[EM_TILE + tl] + scratch[2 * EM_TILE + tl] +
               scratch[3 * EM_TILE + tl];
         nrm = sqrt(nrm);
-        if (nrm == 0.0) nrm = GSS_TINY;
+        if (nrm < GSS_TINY) nrm = GSS_TINY;      // np.maximum(norm, tiny): NaN stays NaN
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int d = g + 4 * j;

@@ -512,6 +512,27 @@ def test_cacgmm_activity_longer_than_obs_is_cut(gpu_ctx):
     assert np.array_equal(a, b)
 
 
+def test_cacgmm_frames_of_zero_and_of_denormal_norm(gpu_ctx):
+    """upstream's normalize_observation divides by maximum(norm, tiny): an all-zero frame stays
+    zero and a frame whose norm is a denormal number is divided by tiny, not by its norm (its
+    normalised length is < 1).  Both the 24-channel and the one-array (one launch) EM."""
+    from pb_chime5_amd import ops
+    for D, T, K in ((4, 300, 3), (24, 200, 4), (12, 150, 3)):
+        rng = np.random.default_rng(D)
+        Y, act = _scene(rng, D, T, 3, K)
+        Y[:, 17, :] = 0.0
+        Y[:, 90, 1] = 0.0
+        Y[:, 40, :] = (crandn(rng, D, 3) * 1e-310)                 # every entry a denormal number
+        Y[:, 130, 2] = 3e-320
+        # (the SQUARED norm of such a frame underflows to zero in float64, upstream's and the
+        # kernel's alike: the frame is divided by tiny and keeps a length of ~ 1e-2)
+        assert np.linalg.norm(Y[:, 40, 0]) == 0 and np.any(Y[:, 40, 0] != 0)
+        got = ops.cacgmm_posteriors(Y, act, 4, 1, ctx=gpu_ctx)
+        want = oracle.gss_block(Y, act, 4, 1)
+        assert np.all(np.isfinite(got))
+        assert np.max(np.abs(got - want)) < 1e-7
+
+
 def test_cacgmm_invariant_to_per_frame_scaling(gpu_ctx):
     from pb_chime5_amd import ops
     rng = np.random.default_rng(6)

@@ -250,7 +250,7 @@ def brute_force_guided_em(obs, activity, iterations, iterations_post=1):
     T, D = obs.shape
     K = activity.shape[0]
     nrm = np.linalg.norm(obs, axis=1)
-    y = obs / np.where(nrm == 0, tiny, nrm)[:, None]                  # (T, D), unit norm
+    y = obs / np.maximum(nrm, tiny)[:, None]                  # (T, D), unit norm
 
     def m_step(gamma, quad):
         covs, pis = [], []

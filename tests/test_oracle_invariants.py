@@ -172,3 +172,22 @@ def test_config3_item_lengths_are_seeded():
     frames = [(c + 480000 + 2 * 768 - 1024 + 255) // 256 + 1 for c in cores]
     assert min(frames) >= 1906 and max(frames) <= 2816
     assert len(set(cores)) > 500
+
+
+def test_normalize_observation_is_maximum_of_norm_and_tiny():
+    """upstream: y / maximum(norm, tiny) -- zero frames stay zero, a frame of denormal norm is
+    divided by tiny (and does NOT come out with unit length), NaN stays NaN."""
+    tiny = np.finfo(np.float64).tiny
+    y = np.zeros((5, 3), complex)
+    y[1] = [3.0, 4.0j, 0.0]
+    y[2] = [3e-310, 4e-310j, 0.0]                       # norm 5e-310 < tiny
+    y[3] = [np.nan, 1.0, 0.0]
+    y[4] = [tiny, 0.0, 0.0]                             # norm == tiny: unit length
+    yn = oracle.normalize_observation(y)                # (D, T)
+    assert yn.shape == (3, 5)
+    assert np.all(yn[:, 0] == 0)
+    assert np.allclose(yn[:, 1], [0.6, 0.8j, 0.0])
+    assert np.array_equal(yn[:, 2], y[2] / tiny)
+    assert abs(np.linalg.norm(yn[:, 2]) - 5e-310 / tiny) < 1e-12
+    assert np.isnan(yn[0, 3])
+    assert yn[0, 4] == 1.0
