@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "gss_internal.h"
+#include <type_traits>
 #include "dense_wave.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -170,7 +171,8 @@ struct CorrTile {
 // 3M complex product: with t1 = sum ar br, t2 = sum ai bi, t3 = sum (ar+ai)(br-bi)
 //   re(a conj b) = t1 + t2,   im(a conj b) = t3 - t1 + t2
 // -- three real MFMAs per tile and k-step instead of four.
-template <int TS, int MASK>
+// KSTEPS: k-steps of the chunk that are run (frames 0 .. 4 KSTEPS - 1 of the window).
+template <int TS, int MASK, int KSTEPS = CORR_KT / 4>
 __device__ __forceinline__ void corr_chunk(const cplx *S, const double *wS, int D,
                                            const CorrTile &tl, v4d (&t1)[TS][TS],
                                            v4d (&t2)[TS][TS], v4d (&t3)[TS][TS]) {
@@ -187,7 +189,7 @@ __device__ __forceinline__ void corr_chunk(const cplx *S, const double *wS, int 
         for (int a = 0; a < TS; ++a) r = r || need(a, b);
         return r;
     };
-    const int ksteps = CORR_KT / 4;
+    const int ksteps = KSTEPS;
     // operands of k-step ks+1 are fetched from LDS while the MFMAs of ks run
     cplx a_cur[TS], b_cur[TS], a_nxt[TS], b_nxt[TS];
     double w_cur, w_nxt = 0.0;
@@ -202,7 +204,7 @@ __device__ __forceinline__ void corr_chunk(const cplx *S, const double *wS, int 
     }
     // (one-sub-tile waves are not unrolled all the way: hoisting 16 k-steps of operand
     // loads costs the registers that let a fourth and fifth wave share the SIMD)
-    constexpr int KU = TS == 1 ? 4 : 16;
+    constexpr int KU = TS == 1 || KSTEPS < 16 ? 4 : 16;
 #pragma unroll KU
     for (int ks = 0; ks < ksteps; ++ks) {
         if (ks + 1 < ksteps) {
@@ -586,18 +588,35 @@ __device__ __forceinline__ void corr_item_dma(
 #pragma unroll
             for (int bb = 0; bb < TS; ++bb) sre[a][bb] = sim[a][bb] = (v4d){0.0, 0.0, 0.0, 0.0};
     }
-    for (int64_t t0 = 0; t0 < T; t0 += CORR_KT, b ^= 1) {
+    // One chunk (window b).  SHORT: the last chunk of the frequency when it holds at most
+    // CORR_KT - 16 frames -- the k-steps past the last frame multiply the zeros the window and
+    // the weights are padded with (4 of 240 k-steps at T = 941, a tenth of the MFMAs of a 3 s
+    // utterance), so only its groups of four k-steps (16 frames) that hold frames are run; the
+    // sums are the same (the skipped terms are + 0.0).  It is a peeled iteration BEHIND the loop
+    // of full chunks: as a branch inside that loop it cost the loop its register allocation
+    // (173 -> 286 registers, accumulators copied between VGPRs and AGPRs around the MFMAs).
+    auto chunk_iter = [&](int64_t t0, auto short_tag) {
+        constexpr bool SHORT = decltype(short_tag)::value;
 #ifdef GSS_CORR_TRACE
         const long long ta = clock64();
 #endif
-        if (t0 + CORR_KT < T)
+        if (!SHORT && t0 + CORR_KT < T)
             issue(f, t0 + CORR_KT, b ^ 1);
         else if (f_next >= 0)
             issue(f_next, 0, b ^ 1);          // the next item's first window
 #ifdef GSS_CORR_TRACE
         const long long tb = clock64();
 #endif
-        if (active) corr_chunk<TS, MASK>(S0 + b * win, w0 + b * CORR_KT, D, tl, t1, t2, t3);
+        if (active) {
+            if constexpr (SHORT) {
+                const int frames = (int)(T - t0);
+                for (int g = 0; 16 * g < frames; ++g)
+                    corr_chunk<TS, MASK, 4>(S0 + b * win + 16 * g * D, w0 + b * CORR_KT + 16 * g, D,
+                                            tl, t1, t2, t3);
+            } else {
+                corr_chunk<TS, MASK>(S0 + b * win, w0 + b * CORR_KT, D, tl, t1, t2, t3);
+            }
+        }
         if constexpr (BLOCKED) if (active) {
 #pragma unroll
             for (int a = 0; a < TS; ++a)
@@ -630,7 +649,11 @@ __device__ __forceinline__ void corr_item_dma(
             g_corr_phase[blockIdx.x * 4 + 3] += te - td;     // barrier
         }
 #endif
-    }
+        b ^= 1;
+    };
+    int64_t t0 = 0;
+    for (; T - t0 > CORR_KT - 16; t0 += CORR_KT) chunk_iter(t0, std::false_type{});
+    if (t0 < T) chunk_iter(t0, std::true_type{});
     if (active)
     {
         if constexpr (BLOCKED) corr_store<TS, MASK, true>(tl, f, n, c, D, sre, sre, sim, R, P);    // (re, -, im)
@@ -1395,6 +1418,9 @@ __global__ __launch_bounds__(64 * NWV) void wpe_apply_kernel(const cplx *__restr
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
     const int wf0 = wave * WAVE_FRAMES;          // first frame of this wave, tile relative
+    // (no barrier below: a wave whose frames all lie past the last one -- two of the 32 wave
+    // tiles at T = 941 -- leaves its SIMD to the other workgroup's wave)
+    if (t0 + wf0 >= T) return;
     v4d acc_re[TA][NB], acc_im[TA][NB], acc_t2[TA][NB];
 #pragma unroll
     for (int a = 0; a < TA; ++a)
@@ -1602,6 +1628,7 @@ __global__ __launch_bounds__(256) void wpe_apply_packed_kernel(const cplx *__res
     const int gzero = GLDS ? n * DG : 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
+    if (t0 + (int64_t)16 * wave * PH >= T) return;          // (no barrier below) all frames past the end
     const int row = 16 * wave + li;                         // A row of this lane: frames PH row + p
     const int abase = row * (PH * DP + 1);                  // LDS address of frame PH row
     const int Kp = n + (PH - 1) * D;
