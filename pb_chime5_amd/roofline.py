@@ -76,11 +76,16 @@ def kernel_work(name, *, F, T, D, K, taps, N, iterations=20):
         c = (n // D) + 1 if D else 0          # delay 2: c = taps + 1 frames back
         if D <= 12 and (c * D) // 16 == (c * D + D - 1) // 16 == sub - 1:
             subtiles = sub * (sub + 1) // 2   # P sits in R's last column tile (one array)
+        # frames the MFMAs run over: chunks of 64 (16 k-steps); the persistent 32 x 32 kernel
+        # (more than 48 sub-tiles) runs a last chunk of at most 48 frames in groups of 16
+        rem = T % 64
+        t_exec = T - rem + (0 if rem == 0 else 64 if rem > 48 or subtiles <= 48
+                            else 16 * -(-rem // 16))
         # bytes: the observation and the frame weights in, the needed entries of R and P out
         return dict(flops=F * 6.0 * need * T, bytes=BY + 8.0 * F * T + 16.0 * F * need,
                     bound='mfma',
                     dense_flops=F * (8.0 * n * n * T + 8.0 * n * D * T),
-                    executed_flops=F * 6.0 * subtiles * 256 * T)
+                    executed_flops=F * 6.0 * subtiles * 256 * t_exec)
     if name == 'wpe_solve':
         return dict(flops=F * ((8.0 / 3.0) * n ** 3 + 8.0 * n * n * D),
                     bytes=16.0 * F * (n * n + 2 * n * D), bound='mfma')
