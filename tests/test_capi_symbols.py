@@ -140,6 +140,16 @@ def test_step_flops_and_traffic_provenance(tmp_path):
     # the dominant kernel dominates the count, as it dominates the step
     corr = roofline.kernel_work('wpe_corr', **shape)
     assert 0.45 < 3 * corr['executed_flops'] / (r['executed_gflop_per_step'] * 1e9) < 0.6
+    # frames the correlation's MFMAs run over: whole 64-frame chunks, except that the persistent
+    # 32 x 32 kernel runs a short last chunk (<= 48 frames) in groups of 16 (wpe.hip,
+    # corr_item_dma); the executed count never falls below the frames that exist
+    def frames(T, D):
+        w = roofline.kernel_work('wpe_corr', F=1, T=T, D=D, K=5, taps=10, N=0)
+        return w['executed_flops'] / roofline.kernel_work('wpe_corr', F=1, T=64, D=D, K=5, taps=10,
+                                                          N=0)['executed_flops'] * 64
+    assert [round(frames(T, 24)) for T in (941, 944, 945, 960, 961, 1009, 2169, 10)] == \
+        [944, 944, 960, 960, 976, 1024, 2176, 16]
+    assert [round(frames(T, 4)) for T in (941, 2169, 10)] == [960, 2176, 64]
     one = roofline.step_peak_frac(2.3, F=513, T=2169, D=4, K=5, taps=10, N=554490)
     assert one['frac_min_flops'] < one['frac'] < 0.35
     assert roofline.kernel_sources('wpe_corr')[0] == 'wpe.hip'

@@ -162,6 +162,39 @@ def test_wpe_matches_oracle(gpu_ctx, D, T, F, taps, delay, iters):
 
 
 @pytest.mark.parametrize('blocked', [False, True])
+def test_wpe_last_chunk_of_every_length(gpu_ctx, monkeypatch, blocked):
+    """The persistent correlation (more than 12 channels at 10 taps) walks the frames in chunks
+    of 64 and runs a LAST chunk of at most 48 frames in groups of 16 (the k-steps past the last
+    frame multiply zeros): frame counts whose last chunk holds 1 ... 64 frames, on both sides of
+    every group boundary, and utterances shorter than one chunk -- also for the block-wise
+    accumulation (`corr_blocked`)."""
+    from pb_chime5_amd import ops
+    if blocked:
+        monkeypatch.setenv('GSS_VARIANT', 'corr_blocked')
+    rng = np.random.default_rng(64)
+    worst = 0.0
+    D, taps, delay = 16, 9, 2              # 144 unknowns: 54 sub-tiles, the persistent kernel
+    for r in (1, 15, 16, 17, 32, 33, 47, 48, 49, 63, 64):
+        T = 384 + r
+        Y = _reverberant(rng, D, T, 2)
+        got = ops.wpe_dtf(Y, taps, delay, 2, ctx=gpu_ctx)
+        want = oracle.wpe_block(Y, taps, delay, 2)
+        err = np.max(np.abs(got - want)) / np.max(np.abs(Y))
+        worst = max(worst, err)
+        assert err < 1e-8, (T, err)
+        assert gpu_ctx.last_wpe_zero_pivots() == 0
+    # shorter than one chunk: the short chunk is the only one (and the system underdetermined:
+    # both solvers interpolate the frames, see test_wpe_underdetermined_few_frames)
+    for T in (48, 40, 17, 16):
+        Y = _reverberant(rng, D, T, 2)
+        got = ops.wpe_dtf(Y, taps, delay, 1, ctx=gpu_ctx)
+        assert np.all(np.isfinite(got))
+        assert np.array_equal(got[:, :delay], Y[:, :delay])
+        assert np.max(np.abs(got[:, delay + taps:])) < 1e-6 * np.max(np.abs(Y)), T
+    print(f'last chunks of every length, blocked={blocked}: worst {worst:.2e}')
+
+
+@pytest.mark.parametrize('blocked', [False, True])
 def test_wpe_config2_bins_within_oracle_noise_of_extended_precision(gpu_ctx, golden, monkeypatch, blocked):
     """Three bins of the bench workload (24 channels, T = 941, 10 taps; bin 169 was the worst
     bin of the end-to-end test in rounds 1-2) against the weighted least-squares iteration
