@@ -321,19 +321,46 @@ __global__ __launch_bounds__(256) void em_estep_kernel(EmArgs a, const cplx *__r
 template <int NV>
 __global__ __launch_bounds__(256) void em_prepare_kernel(const cplx *__restrict__ Y, int F,
                                                          int64_t T, int D,
-                                                         cplx *__restrict__ Yn) {
+                                                         cplx *__restrict__ Yn,
+                                                         int *__restrict__ zero_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx *ys = reinterpret_cast<cplx *>(smem);                  // D * EM_TS
     double *scratch = reinterpret_cast<double *>(ys + D * EM_TS);
     int f, tile;
-    if (!xcd_group_map((int)((T + EM_TILE - 1) / EM_TILE), F, f, tile)) return;
+    const int ntile = (int)((T + EM_TILE - 1) / EM_TILE);
+    if (!xcd_group_map(ntile, F, f, tile)) return;
     const int tid = threadIdx.x, tl = tid & 63, g = tid >> 6;
     const int64_t t0 = (int64_t)tile * EM_TILE;
     load_tile<true, NV>(Y + (int64_t)f * T * D, D, t0, T, tl, g, ys, scratch);
     __syncthreads();
     const int64_t t = t0 + tl;
+    bool nonzero = false;
     if (t < T)
-        for (int d = g; d < D; d += 4) Yn[((int64_t)f * D + d) * T + t] = ys[d * EM_TS + tl];
+        for (int d = g; d < D; d += 4) {
+            const cplx v = ys[d * EM_TS + tl];
+            Yn[((int64_t)f * D + d) * T + t] = v;
+            nonzero = nonzero || v.x != 0.0 || v.y != 0.0;
+        }
+    // Frames whose normalised observation is EXACTLY zero (digital silence): their quadratic
+    // forms sit on the clamp max(|q|, tiny), which is the one place where the scale of B_k does
+    // not cancel between -D ln q and -ln det -- the frequency then has to take the reference's
+    // eigenvalue-normalised model update (see em_chol_kernel).  One word per (frequency, tile),
+    // written by every workgroup (no initialisation, no atomics).
+    scratch[g * EM_TILE + tl] = nonzero ? 1.0 : 0.0;
+    __syncthreads();
+    const bool zero_frame = t < T && g == 0 &&
+                            scratch[tl] + scratch[EM_TILE + tl] + scratch[2 * EM_TILE + tl] +
+                                    scratch[3 * EM_TILE + tl] == 0.0;
+    const int any_zero = __syncthreads_or(zero_frame ? 1 : 0);
+    if (tid == 0) zero_tiles[(int64_t)f * ntile + tile] = any_zero;
+}
+
+// whether frequency f holds a frame on the clamp (em_prepare_kernel's flags; one wave asks)
+__device__ __forceinline__ bool frequency_has_zero_frames(const int *__restrict__ zero_tiles,
+                                                          int ntile, int f, int lane) {
+    int z = 0;
+    for (int i = lane; i < ntile; i += 64) z |= zero_tiles[(int64_t)f * ntile + i];
+    return __any(z != 0);
 }
 
 template <int K, int D, int MODE>
@@ -1018,7 +1045,9 @@ __device__ inline void store_covariance(const cplx (&vals)[COV_SLOTS], int D, do
 // The reference keeps (V, lambda) with lambda <- max(lambda / lambda_max, 1e-10) and
 // evaluates q = y^H V diag(1/lambda) V^H y and ln det = sum ln lambda.  A per-class
 // scale of lambda cancels between -D ln q and -ln det, and rescales the next
-// covariance by a constant that the next normalisation removes again.  So whenever
+// covariance by a constant that the next normalisation removes again -- unless a frame sits
+// on the clamp q = max(|q|, tiny) (an all-zero frame: digital silence), where q does not scale;
+// frequencies with such frames take the eigendecomposition (em_prepare_kernel flags them).  So whenever
 // NO eigenvalue is floored -- lambda_min > 1e-10 lambda_max -- B^-1 and ln det B from a
 // Cholesky factorisation give the same posteriors.  The certificate comes out of the
 // quantities computed anyway:  lambda_min >= 1 / ||B^-1||_F  and  lambda_max <= ||B||_F,
@@ -1229,11 +1258,16 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
                                                      double *__restrict__ pi,
                                                      int *__restrict__ need_eigh,
                                                      const int *__restrict__ tri_tab,
-                                                     MsegPlan plan) {
+                                                     MsegPlan plan,
+                                                     const int *__restrict__ zero_tiles, int ntile) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NE = tri_count(D);
     cplx *A = reinterpret_cast<cplx *>(smem);                  // D * (8 NR + 1) + D doubles
     const int k = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    // A frequency with all-zero frames takes the eigendecomposition for every class: on the
+    // clamp q = max(|q|, tiny) a per-class scale of lambda does NOT cancel (see below), and the
+    // reference's eigenvalues are normalised by their maximum.
+    const bool clamped = frequency_has_zero_frames(zero_tiles, ntile, f, lane);
     const int cnt = plan.S > 0 ? mseg_count(plan, f) : nch;
 
     CHOL_STAMP(0);
@@ -1252,7 +1286,7 @@ __global__ __launch_bounds__(64) void em_chol_kernel(const cplx *__restrict__ Bp
 #if GSS_CHOL_PRIO
     __builtin_amdgcn_s_setprio(2);
 #endif
-    bool fast = !force_eigh && tr > 0.0 && isfinite(tr);
+    bool fast = !force_eigh && !clamped && tr > 0.0 && isfinite(tr);
     if (fast)
         fast = class_update_chol<NR>(vals, D, K, eig_floor, A, lane, Mq + (int64_t)f * NE * K + k,
                                      logdet + f * K + k, ts, tri_tab + NE);
@@ -1338,6 +1372,8 @@ struct OnchipArgs {
     const uint8_t *act;     // (K, act_stride)
     int64_t act_stride, T;
     int F, iterations, iterations_post, force_eigh;
+    const int *zero_tiles;  // (F, ntile) em_prepare_kernel's flags: frames on the clamp
+    int ntile;
     int cold_eigh;          // GSS_VARIANT em4_cold_eigh: every eigendecomposition from the identity
     double eig_floor;
     double *gamma;          // (F, K, T)
@@ -1487,6 +1523,10 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
     const int mi = lane >> 2, msl = lane & 3;         // phase M: entry number, frame slice
     const TriSlots ts = tri_slots(D, lane);
     if (tid < K) basis_validS[tid] = 0;         // (published by the barriers of the first update)
+    // every class through the eigendecomposition: asked for, or the frequency holds all-zero
+    // frames (on the clamp of q the scale of B_k does not cancel, see em_chol_kernel)
+    const bool force_exact = a.force_eigh != 0 ||
+                             frequency_has_zero_frames(a.zero_tiles, a.ntile, f, lane);
 
 #ifdef GSS_EM4_TRACE
     long long em4_acc[6] = {0, 0, 0, 0, 0, 0};
@@ -1701,7 +1741,7 @@ __global__ __launch_bounds__(256, 3) void em_onchip4_kernel(OnchipArgs a) {
             double b[NP], m[NP], ld;
 #pragma unroll
             for (int i = 0; i < NP; ++i) b[i] = bS[k][i];
-            const bool fast = class_update4_lane(b, a.eig_floor, m, ld) && !a.force_eigh;
+            const bool fast = class_update4_lane(b, a.eig_floor, m, ld) && !force_exact;
             if (fast) {
 #pragma unroll
                 for (int i = 0; i < NP; ++i) mR[i][k] = m[i];
@@ -2140,7 +2180,7 @@ struct EmBlock {
     EmArgs a;
     int F;
     cplx *Mq, *Yn;
-    int *need_eigh;
+    int *need_eigh, *zero_tiles;
     double *Sg_lds, *Sg_reg;
     int nch_lds, reg_nch, bp_nch, sg_nch;
     hipStream_t stream;
@@ -2173,9 +2213,13 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
     cplx *Yn = arena_alloc_t<cplx>(ctx, (size_t)F * D * T);
     double *Sg_reg = arena_alloc_t<double>(ctx, (size_t)F * st.reg_nch * K);
     int *need_eigh = arena_alloc_t<int>(ctx, (size_t)F * K);
+    // per (frequency, 64-frame tile): holds a frame whose normalised observation is zero
+    const int ntile = (int)((T + EM_TILE - 1) / EM_TILE);
+    int *zero_tiles = arena_alloc_t<int>(ctx, (size_t)F * ntile);
     // (d1, d2) of the packed triangle, row-major and column-major order (em_chol / em_eigh)
     int *tri_tab = arena_alloc_t<int>(ctx, 2 * (size_t)NE);
-    GSS_REQUIRE(ctx, Mq && logdet && pi && W && Bp && Sg_lds && Yn && Sg_reg && need_eigh && tri_tab,
+    GSS_REQUIRE(ctx, Mq && logdet && pi && W && Bp && Sg_lds && Yn && Sg_reg && need_eigh && tri_tab &&
+                         zero_tiles,
                 GSS_ERR_NOMEM, "cacgmm workspace");
     GSS_REQUIRE(ctx, em_estep_lds(D, K) <= 160 * 1024 &&
                          wcov_lds_layout(D, std::min(K, 8)).total <= 160 * 1024,
@@ -2221,6 +2265,7 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
         a.gamma = gamma + (int64_t)f0 * K * T;
         b.Yn = Yn + (int64_t)f0 * D * T;
         b.need_eigh = need_eigh + (int64_t)f0 * K;
+        b.zero_tiles = zero_tiles + (int64_t)f0 * ntile;
         b.sg_nch = b.nch_lds;
         return GSS_OK;
     };
@@ -2231,7 +2276,7 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
                           : D <= 24 ? em_prepare_kernel<6> : em_prepare_kernel<8>;
         hipLaunchKernelGGL(prep,
                            dim3(xcd_grid((int)((T + EM_TILE - 1) / EM_TILE), b.F)), dim3(256), plds,
-                           ctx->stream, b.a.Y, b.F, T, D, b.Yn);
+                           ctx->stream, b.a.Y, b.F, T, D, b.Yn, b.zero_tiles);
         GSS_LAUNCH_CHECK(ctx, "em_prepare_kernel");
         return GSS_OK;
     };
@@ -2261,7 +2306,7 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
             hipLaunchKernelGGL(kern, dim3(K, b.F), dim3(64), lds, ctx->stream, a.Bp, a.Sg, b.bp_nch,
                                b.sg_nch, D, K, T, 1e-10, force_eigh, b.Mq,
                                const_cast<double *>(a.logdet), const_cast<double *>(a.pi),
-                               b.need_eigh, tri_tab, a.mseg);
+                               b.need_eigh, tri_tab, a.mseg, b.zero_tiles, ntile);
             GSS_LAUNCH_CHECK(ctx, "em_chol_kernel");
         }
         {
@@ -2289,6 +2334,8 @@ int cacgmm_run(gss_ctx *ctx, const cplx *Y, int F, int64_t T, int D, const uint8
         o.iterations = iterations;
         o.iterations_post = iterations_post;
         o.force_eigh = force_eigh;
+        o.zero_tiles = b.zero_tiles;
+        o.ntile = ntile;
         o.cold_eigh = gss_variant_set("em4_cold_eigh");
         o.eig_floor = 1e-10;
         o.gamma = gamma;

@@ -664,6 +664,36 @@ def test_edge_dead_microphone_takes_the_lstsq_branch(gpu_ctx):
     assert rel_err(got, want) < TOL_STFT_MAG
 
 
+@pytest.mark.parametrize('channels,wpe', [(4, False), (4, True), (6, False), (6, True)])
+def test_edge_block_of_digital_silence_in_every_channel(gpu_ctx, channels, wpe):
+    """Every microphone delivers digital zeros for a while (a dropped block): those STFT frames
+    are exact zeros, their quadratic forms sit on the clamp max(|q|, tiny), and THERE the
+    posterior depends on the eigenvalue normalisation of pb_bss (lambda / lambda_max) -- the one
+    place where the Cholesky form of the model update (B_k up to a scale) is not equivalent.
+    Frequencies that hold such frames take the eigendecomposition for every class
+    (em_prepare_kernel flags them; found by the zero-frame test of the stage in round 6)."""
+    from pb_chime5_amd import synthetic
+    u = synthetic.tiny(seed=11, num_channels=channels, num_samples=30000, num_speakers=3, context=2048)
+    u.obs[:, 9000:17000] = 0.0
+    got, det, want, wdet = _run_both(u, wpe=wpe, wpe_taps=3, wpe_delay=2, wpe_iterations=2,
+                                     bss_iterations=5)
+    zero = np.all(wdet['Obs'] == 0, axis=0)                      # (T, F)
+    assert zero.all(axis=1).sum() >= 20                          # whole frames of zeros reach the EM
+    assert det['ref_channel'] == wdet['ref_channel']
+    # (the reference's masks have their context frames zeroed; elsewhere they are the posteriors)
+    post, masks = det['posterior'], wdet['masks']
+    assert post.shape == masks.shape
+    inside = masks.sum(axis=0) > 0
+    assert inside[zero].sum() > 20 * 100                         # zero frames outside the context
+    # (without the exact path the zero frames differ by 0.1 ... 1; behind WPE the first frames of
+    # the silence hold the filter's prediction alone, whose direction carries the 1e-6 between
+    # the two solvers)
+    assert np.max(np.abs(post - masks)[:, inside]) < (1e-4 if wpe else 1e-6)
+    assert np.max(np.abs(post - masks)[:, inside & zero]) < 1e-6
+    assert rel_err(np.abs(det['X_hat']), np.abs(wdet['X_hat'])) < TOL_STFT_MAG
+    assert rel_err(got, want) < TOL_STFT_MAG
+
+
 def test_edge_all_zero_observation_gives_nan_like_reference(gpu_ctx):
     """Digital silence: PSD matrices are zero, solve falls back to lstsq -> w = 0, and
     BAN divides 0 / 0 (eps = 0 upstream), so the reference returns NaN everywhere.
