@@ -36,6 +36,8 @@ run bf python tools/fuzz_bf.py 46 600
 run em python tools/fuzz_em.py 47 700
 run em_one_array env GSS_FUZZ_D=4 GSS_FUZZ_KMAX=6 GSS_FUZZ_TMAX=1200 python tools/fuzz_em.py 48 500   # em_onchip4_kernel
 run em_blocks env GSS_VARIANT=em_l3_fit_mb=0,em_l3_mb=1 python tools/fuzz_em.py 56 200          # EM over blocks of frequencies, two streams
+run em_zero_frames env GSS_FUZZ_ZEROS=1 python tools/fuzz_em.py 57 300        # digital silence: the eigenvalue-normalised update
+run em_zero_frames_one_array env GSS_FUZZ_ZEROS=1 GSS_FUZZ_D=4 GSS_FUZZ_KMAX=6 GSS_FUZZ_TMAX=1200 python tools/fuzz_em.py 58 200
 for seed in 49 50 51; do run session_$seed python tools/fuzz_session.py $seed 24; done
 run session_gev python tools/fuzz_session.py 52 24 gev_ban
 # machine-written total: every "failures N" / "N failed" / non-zero exit status of the sweeps above

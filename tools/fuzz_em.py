@@ -11,7 +11,8 @@ em_yardstick): GPU - referee <= 5 x yardstick + 1e-9.  (Until round 5 the
 yardstick was 30 x the distance between the oracle and a brute-force float64 EM that shares
 LAPACK's eigh with it -- a ratio between two float64 programs, with one case at 35.7 explained by
 hand two rounds running.)  The last line is a machine-written tally.
-    python tools/fuzz_em.py [SEED] [CASES]"""
+    python tools/fuzz_em.py [SEED] [CASES]
+GSS_FUZZ_ZEROS=1: every case with a block of frames that are zero in every channel."""
 import os
 import sys
 import warnings
@@ -62,6 +63,21 @@ def main():
         src = (rng.standard_normal((F, K, T)) + 1j * rng.standard_normal((F, K, T))) * act[None]
         obs = np.einsum('fkd,fkt->dtf', steer, src)
         obs = obs + 10.0 ** rng.uniform(-2, 0) * (rng.standard_normal(obs.shape) + 1j * rng.standard_normal(obs.shape))
+        if os.environ.get('GSS_FUZZ_ZEROS'):
+            # digital silence: frames that are zero in every channel (their quadratic forms sit
+            # on the clamp max(|q|, tiny), where the eigenvalue normalisation of pb_bss shows --
+            # EXPERIMENTS round 6, item 12); a generator of its own: the stream above is the same
+            # with and without
+            zr = np.random.default_rng([seed, case, 12])
+            nz = int(zr.integers(1, max(2, T // 3)))
+            a = int(zr.integers(0, T))
+            zt = np.zeros(T, bool)
+            zt[a:a + nz] = True                                  # a block ...
+            zt[zr.integers(0, T, size=int(zr.integers(0, 4)))] = True    # ... and stray frames
+            if zr.integers(0, 3) == 0:
+                obs[:, zt, int(zr.integers(0, F))] = 0.0         # one frequency only
+            else:
+                obs[:, zt, :] = 0.0
         tag = dict(case=case, D=D, K=K, T=T, F=F, it=it, post=post, active=act.sum(axis=1).tolist())
         # GSS_FUZZ_ONLY=case: replay one case of the stream (the draws of the others are consumed)
         if os.environ.get('GSS_FUZZ_ONLY') and case != int(os.environ['GSS_FUZZ_ONLY']):
