@@ -317,6 +317,35 @@ def test_guided_em_by_brute_force(iterations, post):
     assert np.max(np.abs(got - want)) < 1e-9
 
 
+def test_guided_em_with_frames_of_digital_silence_by_brute_force():
+    """Frames that are zero in every channel sit on the clamp max(|q|, tiny): there -- and only
+    there -- the posterior shows that pb_bss divides a class's eigenvalues by the largest one
+    (ln det of the NORMALISED covariance).  Oracle and brute force agree on it; a model update
+    that keeps B_k at another scale (the Cholesky form of the HIP path before round 6) is off by
+    lambda_max^-D per class at those frames."""
+    rng = np.random.default_rng(12)
+    obs, act = guided_scene(rng, K=3, D=4, T=120)
+    obs[30:55] = 0.0
+    obs[90] = 0.0
+    for iterations, post in ((1, 1), (4, 1), (3, 0)):
+        want = brute_force_guided_em(obs, act, iterations, post)
+        got = oracle.gss_block(obs.T[:, :, None], act, iterations, post)[..., 0]
+        assert np.max(np.abs(got - want)) < 1e-9
+        # the posterior of a zero frame is the same at every zero frame with the same activity
+        # (it depends on the model alone) ...
+        assert np.allclose(got[:, 31], got[:, 54]) or not np.array_equal(act[:, 31], act[:, 54])
+    # ... and a per-class rescaling of the covariances would change it: the clamp does not scale
+    lam_max = []
+    tiny = np.finfo(float).tiny
+    y = obs / np.maximum(np.linalg.norm(obs, axis=1), tiny)[:, None]
+    gamma = np.where(act, 1.0, 1e-10)
+    gamma = gamma / gamma.sum(axis=0)
+    for k in range(3):
+        B = 4 * (y.T * gamma[k]) @ y.conj() / gamma[k].sum()
+        lam_max.append(np.linalg.eigvalsh((B + B.conj().T) / 2).max())
+    assert max(lam_max) / min(lam_max) > 1.05          # the classes' scales do differ
+
+
 # ---------------------------------------------------------------- beamformer
 def _scene(rng, F=6, D=5, T=90):
     Y = crandn(rng, F, D, T)
