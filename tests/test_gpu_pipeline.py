@@ -944,10 +944,12 @@ def _wpe_stage_ok(det, wdet, taps, delay, iterations, kw=None):
     return max(dg) <= 3 * max(max(do), 1e-9) and all(g <= 10 * max(o, 1e-9) for g, o in zip(dg, do))
 
 
-def _fuzz_case(gpu_ctx, ref_mismatches, case, D, K, N, ctx_s, kw, wide=False):
+def _fuzz_case(gpu_ctx, ref_mismatches, case, D, K, N, ctx_s, kw, wide=False, mutate=None):
     from pb_chime5_amd import ops, synthetic
     u = synthetic.tiny(seed=5000 + case, num_channels=D, num_samples=N, num_speakers=K - 1,
                        context=ctx_s, noise=5e-2)
+    if mutate is not None:
+        mutate(u)            # tools/fuzz_silence.py: blocks of digital silence in the recording
     bf = kw['bf']
     tag = (case, D, K, N, kw)
     raised = []

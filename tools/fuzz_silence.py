@@ -1,0 +1,64 @@
+"""Digital silence through the whole pipeline against the oracle: the wide parameter draws of
+tests/fuzz_params.py (channel / class / frame counts, window lengths, WPE and EM settings, MVDR /
+GEV / postfilter), every case with a dropped, zero-filled block in the recording -- every
+channel for a while, the channels of one "array", everything before or after some point, two
+blocks -- and judged by the pipeline sweep's own rules (tests/test_gpu_pipeline.py::_fuzz_case:
+well-conditioned bins against the literal oracle, the others against the extended-precision
+referees, one-sided exceptions, reference-channel ties).  Exact zeros are where reformulations
+stop being equivalent (the clamp of the CACG quadratic form: EXPERIMENTS round 6, item 12), and
+no other sweep draws them.
+    python tools/fuzz_silence.py [SEED] [CASES]"""
+import sys
+import warnings
+from pathlib import Path
+
+import numpy as np
+
+R = Path(__file__).resolve().parents[1]
+for p in (str(R), str(R / 'oracle'), str(R / 'tests')):
+    sys.path.insert(0, p)
+
+
+def main():
+    import fuzz_params
+    import test_gpu_pipeline as tp
+    from pb_chime5_amd._capi import default_context
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    warnings.simplefilter('ignore')
+    ctx = default_context(0)
+    mismatches, failures, notes, done = [], 0, {}, 0
+    for case, D, K, N, ctx_s, kw in fuzz_params.fuzz_cases(seed, cases, True):
+        zr = np.random.default_rng([seed, case, 13])
+        kind = int(zr.integers(0, 5))
+        a = int(zr.integers(0, max(1, N - 6000)))
+        b = a + int(zr.integers(1500, 12000))
+        a2 = int(zr.integers(0, max(1, N - 3000)))
+
+        def mutate(u, kind=kind, a=a, b=b, a2=a2, D=D):
+            if kind == 0:
+                u.obs[:, a:b] = 0.0                               # every channel for a while
+            elif kind == 1:
+                u.obs[:, :b] = 0.0                                # the recording starts late
+            elif kind == 2:
+                u.obs[:, a:] = 0.0                                # ... or ends early
+            elif kind == 3:
+                u.obs[:max(1, D // 2), a:b] = 0.0                 # one "array" drops out
+            else:
+                u.obs[:, a:b] = 0.0                               # two blocks
+                u.obs[:, a2:a2 + 2500] = 0.0
+        try:
+            note = tp._fuzz_case(ctx, mismatches, case, D, K, N, ctx_s, kw, wide=True, mutate=mutate)
+        except AssertionError as e:
+            print('FAILED', dict(case=case, kind=kind, a=a, b=b), str(e)[:700])
+            failures += 1
+            note = 'failed'
+        note = f'{note}'
+        notes[note] = notes.get(note, 0) + 1
+        done += 1
+    print('silence fuzz: seed', seed, 'cases', done, 'failures', failures, notes)
+    print('reference-channel mismatches:', mismatches)
+
+
+if __name__ == '__main__':
+    main()
