@@ -991,7 +991,8 @@ def _fuzz_case(gpu_ctx, ref_mismatches, case, D, K, N, ctx_s, kw, wide=False, mu
                            postfilter=kw['postfilter'])
         blocks = enh.enhance_observation(u.obs, u.activity, u.speaker_id, ex=u.ex, fused=False)
         assert blocks.shape == got.shape, tag
-        if bf != 'gev_ban':     # (a generalised eigenvector's phase: two kernels, two answers)
+        assert np.array_equal(np.isnan(blocks), np.isnan(got)), (tag, 'block path vs fused: NaN pattern')
+        if bf != 'gev_ban' and not np.isnan(got).any():     # (a generalised eigenvector's phase: two kernels, two answers)
             scale = max(np.abs(got).max(), 1e-300)
             assert np.max(np.abs(blocks - got)) < 1e-9 * scale, \
                 (tag, 'block path vs fused', np.max(np.abs(blocks - got)) / scale)

@@ -39,8 +39,8 @@ run em_blocks env GSS_VARIANT=em_l3_fit_mb=0,em_l3_mb=1 python tools/fuzz_em.py 
 run em_zero_frames env GSS_FUZZ_ZEROS=1 python tools/fuzz_em.py 57 300        # digital silence: the eigenvalue-normalised update
 run em_zero_frames_one_array env GSS_FUZZ_ZEROS=1 GSS_FUZZ_D=4 GSS_FUZZ_KMAX=6 GSS_FUZZ_TMAX=1200 python tools/fuzz_em.py 58 200
 # the wide pipeline draws with a dropped, zero-filled block in every recording
-run pipeline_silence_61 timeout 1500 python tools/fuzz_silence.py 61 120
-run pipeline_silence_62 timeout 1500 python tools/fuzz_silence.py 62 120
+run pipeline_silence_61 timeout 1500 python tools/fuzz_silence.py 61 200
+run pipeline_silence_62 timeout 1500 python tools/fuzz_silence.py 62 200
 for seed in 49 50 51; do run session_$seed python tools/fuzz_session.py $seed 24; done
 run session_gev python tools/fuzz_session.py 52 24 gev_ban
 # machine-written total: every "failures N" / "N failed" / non-zero exit status of the sweeps above
