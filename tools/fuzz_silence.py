@@ -8,6 +8,7 @@ referees, one-sided exceptions, reference-channel ties).  Exact zeros are where 
 stop being equivalent (the clamp of the CACG quadratic form: EXPERIMENTS round 6, item 12), and
 no other sweep draws them.
     python tools/fuzz_silence.py [SEED] [CASES]"""
+import os
 import sys
 import warnings
 from pathlib import Path
@@ -17,6 +18,32 @@ import numpy as np
 R = Path(__file__).resolve().parents[1]
 for p in (str(R), str(R / 'oracle'), str(R / 'tests')):
     sys.path.insert(0, p)
+
+
+def replay_wpe(tp, ctx, case, D, K, N, ctx_s, kw, mutate):
+    import ext_precision
+    import gss_oracle as oracle
+    from pb_chime5_amd import ops, synthetic
+    u = synthetic.tiny(seed=5000 + case, num_channels=D, num_samples=N, num_speakers=K - 1,
+                       context=ctx_s, noise=5e-2)
+    mutate(u)
+    Y = oracle.stft(u.obs, kw.get('stft_size', 1024), kw.get('stft_shift', 256),
+                    fading=kw.get('stft_fading', True))
+    Xo = oracle.wpe_block(Y, kw['wpe_taps'], kw['wpe_delay'], kw['wpe_iterations'],
+                          kw.get('wpe_psd_context', 0))
+    Xg = ops.wpe_dtf(Y, kw['wpe_taps'], kw['wpe_delay'], kw['wpe_iterations'],
+                     kw.get('wpe_psd_context', 0), ctx=ctx)
+    n = np.linalg.norm
+    per = np.array([n(Xg[..., f] - Xo[..., f]) / max(n(Xo[..., f]), 1e-300) for f in range(Xg.shape[-1])])
+    print('replay: WPE GPU - oracle', tp.rel_err(Xg, Xo), 'GSS_VARIANT', os.environ.get('GSS_VARIANT', ''))
+    for f in np.argsort(per)[::-1][:4]:
+        Yf = np.ascontiguousarray(Y[..., f])
+        Yt = oracle.build_y_tilde(Yf, kw['wpe_taps'], kw['wpe_delay'])
+        Xt = ext_precision.wpe(Yf, Yt, kw['wpe_iterations'])[-1]
+        w = oracle.get_power_inverse(Yf)
+        R = (Yt * w) @ Yt.conj().T
+        print('  frequency', int(f), 'cond(R)', f'{np.linalg.cond(R):.1e}', 'GPU - referee',
+              f'{n(Xg[..., f] - Xt) / n(Xt):.2e}', 'oracle - referee', f'{n(Xo[..., f] - Xt) / n(Xt):.2e}')
 
 
 def main():
@@ -58,6 +85,11 @@ def main():
             else:
                 u.obs[:, a:b] = 0.0                               # two blocks
                 u.obs[:, a2:a2 + 2500] = 0.0
+        if os.environ.get('GSS_FUZZ_ONLY'):
+            # replay one case: the WPE stage against the 80-bit iteration, frequency by frequency
+            if case != int(os.environ['GSS_FUZZ_ONLY']):
+                continue
+            replay_wpe(tp, ctx, case, D, K, N, ctx_s, kw, mutate)
         try:
             note = tp._fuzz_case(ctx, mismatches, case, D, K, N, ctx_s, kw, wide=True, mutate=mutate)
         except AssertionError as e:
